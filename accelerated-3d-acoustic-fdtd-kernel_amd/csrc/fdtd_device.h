@@ -1,0 +1,40 @@
+// fdtd_device.h — shared declarations of the gfx950 kernels and their launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fdtd_abi.h"
+
+// Everything a stencil sweep needs, passed by value in the kernarg segment (scalar
+// loads, no per-thread cost).  Level pointers already include the ring offset.
+struct StencilArgs {
+  const float *m;
+  const float *u0;  // level t0 (current)
+  const float *u1;  // level t1 (previous)
+  float *u2;        // level t2 (next, written)
+  long sx, sy;      // element strides of one x / one y step (nyp*nzp, nzp)
+  int nxp, nyp, nzp;
+  int x_m, x_M, y_m, y_M, z_m, z_M;
+  float dt2;        // dt*dt, rounded once on the host like the reference does
+  float r1, r2, r3, r4;
+};
+
+// Source scatter arguments.
+struct InjectArgs {
+  const float *m;
+  const float *src;
+  const float *coords;
+  float *u2;
+  long sx, sy;
+  int x_m, x_M, y_m, y_M, z_m, z_M;
+  float h_x, h_y, h_z, o_x, o_y, o_z;
+  int p_src_m, p_src_M;
+  int time;
+  int src_stride, coord_stride;
+};
+
+#define FDTD_HIP_CHECK(expr)                  \
+  do {                                        \
+    hipError_t _e = (expr);                   \
+    if (_e != hipSuccess) return (int)_e;     \
+  } while (0)

@@ -1,0 +1,362 @@
+// fdtd_operators.hip — host side of the C ABI: the time loop on device-resident fields,
+// the three Devito-style operators (host buffers in, host buffers out) and the
+// convenience runners.  Device code lives in fdtd_kernels.hip.
+//
+// Reference behaviour mirrored here:
+//   openacc.cpp:90-93,148   ring indices and the 5 untimed warm-up steps
+//   cuda.cu:183             deviceid != -1 selects the device
+//   cuda.cu:204-214,317-320 copy all of u (3 levels, halos included), m, src, coords in;
+//                           copy all of u back; free every device buffer before return
+//   cuda.cu:246,288         sources are injected iff p_src_M >= p_src_m
+//   openacc.cpp:3           timers are accumulated, in seconds
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fdtd_device.h"
+
+static int g_cfg_use_tc = 0, g_cfg_t_fuse = 1, g_cfg_nfields = 1;
+
+extern "C" void FDTD_SetRuntimeConfig(int use_tc, int t_fuse, int nfields) {
+  g_cfg_use_tc = use_tc;
+  g_cfg_t_fuse = t_fuse;
+  g_cfg_nfields = nfields;
+}
+
+extern "C" const char *fdtd_hip_version(void) {
+  return "fdtd-hip gfx950 variants=flat,naive,march,tile3d storage=f32,f16";
+}
+
+namespace {
+
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  ~EventPool() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+  int make(size_t n) {
+    ev.resize(n, nullptr);
+    for (size_t i = 0; i < n; ++i) FDTD_HIP_CHECK(hipEventCreate(&ev[i]));
+    return 0;
+  }
+};
+
+}  // namespace
+
+// `h16` selects the binary16-storage kernels; u then points at __half data.
+static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, const float *src,
+                          const float *src_coords, void *u, int p_src_m, int p_src_M,
+                          int src_stride, int coord_stride, int time_m, int time_M, int variant,
+                          void *stream, struct profiler *timers) {
+  if (!g || !m || !u) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const bool has_src = (p_src_M >= p_src_m) && src && src_coords;
+  if (p_src_M >= p_src_m && !has_src) return (int)hipErrorInvalidValue;
+
+  // Three events per timed step: before the stencil, between the sections, after the
+  // scatter.  They are recorded on the stream without any host synchronisation; the
+  // elapsed times are read once after the final synchronise.
+  const int first_timed = time_m + FDTD_WARMUP_STEPS;
+  const int n_timed = (timers && time_M >= first_timed) ? (time_M - first_timed + 1) : 0;
+  EventPool pool;
+  if (n_timed > 0) {
+    int rc = pool.make((size_t)n_timed * 3);
+    if (rc) return rc;
+  }
+
+  for (int time = time_m; time <= time_M; ++time) {
+    // openacc.cpp:148
+    const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3,
+              t2 = (((time + 1) % 3) + 3) % 3;
+    const int k = (n_timed > 0 && time >= first_timed) ? (time - first_timed) : -1;
+    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(pool.ev[3 * k + 0], s));
+    int rc = h16 ? fdtd_hip_stencil_step_h16(g, m, u, t0, t1, t2, s)
+                 : fdtd_hip_stencil_step(g, m, (float *)u, t0, t1, t2, variant, s);
+    if (rc) return rc;
+    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(pool.ev[3 * k + 1], s));
+    if (has_src) {
+      rc = h16 ? fdtd_hip_source_inject_h16(g, m, src, src_coords, u, t2, time, p_src_m, p_src_M,
+                                            src_stride, coord_stride, s)
+               : fdtd_hip_source_inject(g, m, src, src_coords, (float *)u, t2, time, p_src_m,
+                                        p_src_M, src_stride, coord_stride, s);
+      if (rc) return rc;
+    }
+    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(pool.ev[3 * k + 2], s));
+  }
+  FDTD_HIP_CHECK(hipStreamSynchronize(s));
+
+  if (n_timed > 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < n_timed; ++k) {
+      float ms0 = 0.f, ms1 = 0.f;
+      FDTD_HIP_CHECK(hipEventElapsedTime(&ms0, pool.ev[3 * k + 0], pool.ev[3 * k + 1]));
+      FDTD_HIP_CHECK(hipEventElapsedTime(&ms1, pool.ev[3 * k + 1], pool.ev[3 * k + 2]));
+      s0 += ms0;
+      s1 += ms1;
+    }
+    timers->section0 += s0 * 1e-3;
+    timers->section1 += s1 * 1e-3;
+  }
+  return 0;
+}
+
+extern "C" int fdtd_hip_time_loop(const struct fdtd_geom *g, const float *m, const float *src,
+                                  const float *src_coords, float *u, int p_src_m, int p_src_M,
+                                  int src_stride, int coord_stride, int time_m, int time_M,
+                                  int variant, void *stream, struct profiler *timers) {
+  return time_loop_impl(false, g, m, src, src_coords, u, p_src_m, p_src_M, src_stride, coord_stride,
+                        time_m, time_M, variant, stream, timers);
+}
+
+namespace {
+
+struct DeviceBuffers {
+  float *u = nullptr, *m = nullptr, *src = nullptr, *coords = nullptr;
+  void *u16 = nullptr;  // binary16 copy of u in the fp16-storage mode
+  ~DeviceBuffers() {
+    if (u) (void)hipFree(u);
+    if (u16) (void)hipFree(u16);
+    if (m) (void)hipFree(m);
+    if (src) (void)hipFree(src);
+    if (coords) (void)hipFree(coords);
+  }
+};
+
+// Shape checks shared by the operators.  The reference trusts its caller; a wrong shape
+// there is an out-of-bounds access, here it is hipErrorInvalidValue
+// (cuda_optimized.cu:346-347 does the same for non-positive extents).
+int check_operator_args(const dataobj *m_vec, const dataobj *src_vec, const dataobj *coords_vec,
+                        const dataobj *u_vec, int p_src_M, int p_src_m) {
+  if (!m_vec || !u_vec || !src_vec || !coords_vec) return (int)hipErrorInvalidValue;
+  if (!m_vec->data || !u_vec->data || !m_vec->size || !u_vec->size) return (int)hipErrorInvalidValue;
+  if (u_vec->size[0] != 3) return (int)hipErrorInvalidValue;
+  for (int d = 0; d < 3; ++d)
+    if (u_vec->size[d + 1] <= 0 || m_vec->size[d] != u_vec->size[d + 1]) return (int)hipErrorInvalidValue;
+  if (p_src_M >= p_src_m) {
+    if (!src_vec->data || !coords_vec->data || !src_vec->size || !coords_vec->size)
+      return (int)hipErrorInvalidValue;
+    if (p_src_m < 0 || p_src_M >= src_vec->size[1] || p_src_M >= coords_vec->size[0] ||
+        coords_vec->size[1] < 3)
+      return (int)hipErrorInvalidValue;
+  }
+  return 0;
+}
+
+constexpr int STORAGE_H16 = 100;  // pseudo-variant: binary16 storage
+
+int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_vec, dataobj *u_vec,
+                 int x_M, int x_m, int y_M, int y_m, int z_M, int z_m, float dt, float h_x,
+                 float h_y, float h_z, float o_x, float o_y, float o_z, int p_src_M, int p_src_m,
+                 int time_M, int time_m, int deviceid, profiler *timers) {
+  int rc = check_operator_args(m_vec, src_vec, coords_vec, u_vec, p_src_M, p_src_m);
+  if (rc) return rc;
+  if (deviceid != -1) FDTD_HIP_CHECK(hipSetDevice(deviceid));
+
+  fdtd_geom g;
+  g.nxp = u_vec->size[1]; g.nyp = u_vec->size[2]; g.nzp = u_vec->size[3];
+  g.x_m = x_m; g.x_M = x_M; g.y_m = y_m; g.y_M = y_M; g.z_m = z_m; g.z_M = z_M;
+  g.dt = dt; g.h_x = h_x; g.h_y = h_y; g.h_z = h_z; g.o_x = o_x; g.o_y = o_y; g.o_z = o_z;
+
+  const size_t vol = (size_t)g.nxp * g.nyp * g.nzp;
+  const bool has_src = p_src_M >= p_src_m;
+  // The source section is guarded by size[0]*size[1] > 0 as well (openacc.cpp:173).
+  const bool src_nonempty = has_src && (long)src_vec->size[0] * src_vec->size[1] > 0;
+  if (src_nonempty && (time_M >= src_vec->size[0] || time_m < 0)) return (int)hipErrorInvalidValue;
+  const size_t n_src = src_nonempty ? (size_t)src_vec->size[0] * src_vec->size[1] : 0;
+  const size_t n_coords = src_nonempty ? (size_t)coords_vec->size[0] * coords_vec->size[1] : 0;
+
+  DeviceBuffers d;
+  FDTD_HIP_CHECK(hipMalloc((void **)&d.u, 3 * vol * sizeof(float)));
+  FDTD_HIP_CHECK(hipMalloc((void **)&d.m, vol * sizeof(float)));
+  FDTD_HIP_CHECK(hipMemcpy(d.u, u_vec->data, 3 * vol * sizeof(float), hipMemcpyHostToDevice));
+  FDTD_HIP_CHECK(hipMemcpy(d.m, m_vec->data, vol * sizeof(float), hipMemcpyHostToDevice));
+  if (src_nonempty) {
+    FDTD_HIP_CHECK(hipMalloc((void **)&d.src, n_src * sizeof(float)));
+    FDTD_HIP_CHECK(hipMalloc((void **)&d.coords, n_coords * sizeof(float)));
+    FDTD_HIP_CHECK(hipMemcpy(d.src, src_vec->data, n_src * sizeof(float), hipMemcpyHostToDevice));
+    FDTD_HIP_CHECK(hipMemcpy(d.coords, coords_vec->data, n_coords * sizeof(float), hipMemcpyHostToDevice));
+  }
+
+  const bool h16 = (variant == STORAGE_H16);
+  if (h16) {
+    FDTD_HIP_CHECK(hipMalloc(&d.u16, 3 * vol * sizeof(unsigned short)));
+    rc = fdtd_hip_convert_f32_to_h16(d.u, d.u16, 3 * vol, nullptr);
+    if (rc) return rc;
+  }
+  rc = time_loop_impl(h16, &g, d.m, d.src, d.coords, h16 ? d.u16 : (void *)d.u,
+                      src_nonempty ? p_src_m : 0, src_nonempty ? p_src_M : -1,
+                      src_nonempty ? src_vec->size[1] : 1, src_nonempty ? coords_vec->size[1] : 3,
+                      time_m, time_M, variant, nullptr, timers);
+  if (rc) return rc;
+  if (h16) {
+    rc = fdtd_hip_convert_h16_to_f32(d.u16, d.u, 3 * vol, nullptr);
+    if (rc) return rc;
+  }
+  FDTD_HIP_CHECK(hipMemcpy(u_vec->data, d.u, 3 * vol * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // namespace
+
+#define FDTD_FORWARD(variant)                                                                  \
+  run_operator(variant, m_vec, src_vec, src_coords_vec, u_vec, x_M, x_m, y_M, y_m, z_M, z_m,   \
+               dt, h_x, h_y, h_z, o_x, o_y, o_z, p_src_M, p_src_m, time_M, time_m, deviceid,   \
+               timers)
+
+extern "C" int Kernel_OpenACC(FDTD_OPERATOR_ARGS) {
+  (void)devicerm;
+  return FDTD_FORWARD(FDTD_VARIANT_FLAT);
+}
+
+extern "C" int Kernel_CUDA(FDTD_OPERATOR_ARGS) {
+  (void)devicerm;
+  return FDTD_FORWARD(FDTD_VARIANT_NAIVE);
+}
+
+static int optimized_variant() {
+  const char *v = getenv("FDTD_VARIANT");
+  if (!v) return FDTD_VARIANT_AUTO;
+  if (!strcmp(v, "flat")) return FDTD_VARIANT_FLAT;
+  if (!strcmp(v, "naive")) return FDTD_VARIANT_NAIVE;
+  if (!strcmp(v, "march")) return FDTD_VARIANT_MARCH;
+  if (!strcmp(v, "tile3d")) return FDTD_VARIANT_TILE3D;
+  return FDTD_VARIANT_AUTO;
+}
+
+extern "C" int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS) {
+  (void)devicerm;
+  return FDTD_FORWARD(optimized_variant());
+}
+
+extern "C" int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS) {
+  (void)devicerm;
+  return FDTD_FORWARD(STORAGE_H16);
+}
+
+// ---------------------------------------------------------------------------------
+// Input generators and parity metrics of the reference driver.
+// ---------------------------------------------------------------------------------
+#include <math.h>
+
+extern "C" void fdtd_fill_ricker(float *src, int T, int S, float dt) {
+  // main.cpp:290-298
+  const float f0 = 10.0f;
+  for (int t = 0; t < T; ++t) {
+    const float tshift = t * dt - 1.0f / f0;
+    const float a = float(M_PI) * float(M_PI) * f0 * f0 * tshift * tshift;
+    const float val = (1.0f - 2.0f * a) * expf(-a);
+    for (int s = 0; s < S; ++s) src[(size_t)t * S + s] = val;
+  }
+}
+
+extern "C" void fdtd_fill_source_coords(float *coords, int S, int nx, int ny, int nz) {
+  // main.cpp:301-325
+  const float h = 0.1f;
+  const int n[3] = {nx, ny, nz};
+  float tick[3][3];
+  for (int d = 0; d < 3; ++d) {
+    const float L = (n[d] - 1) * h;
+    tick[d][0] = 0.25f * L;
+    tick[d][1] = 0.50f * L;
+    tick[d][2] = 0.75f * L;
+  }
+  int placed = 0;
+  for (int i = 0; i < 3 && placed < S; ++i)
+    for (int j = 0; j < 3 && placed < S; ++j)
+      for (int k = 0; k < 3 && placed < S; ++k) {
+        coords[3 * placed + 0] = tick[0][i];
+        coords[3 * placed + 1] = tick[1][j];
+        coords[3 * placed + 2] = tick[2][k];
+        ++placed;
+      }
+  for (; placed < S; ++placed) {
+    coords[3 * placed + 0] = 0.5f * (nx - 1) * h;
+    coords[3 * placed + 1] = 0.5f * (ny - 1) * h;
+    coords[3 * placed + 2] = 0.5f * (nz - 1) * h;
+  }
+}
+
+extern "C" void fdtd_fill_correctness_inputs(float *u, float *m, size_t volp) {
+  // main.cpp:525-532; the third level is zeroed explicitly (the driver leaves it to the
+  // allocator, and the published parity numbers assume fresh zero pages).
+  for (size_t i = 0; i < volp; ++i) {
+    m[i] = 1.5f;
+    const float val = sinf(i * 0.001f) * 10.0f + 100.0f;
+    u[i] = u[volp + i] = val;
+    u[2 * volp + i] = 0.0f;
+  }
+}
+
+extern "C" void fdtd_compare_fields(const float *test, const float *ref, size_t n,
+                                    struct fdtd_parity *out) {
+  // main.cpp:573-593
+  double max_abs = 0.0, max_rel = 0.0, l2_diff = 0.0, l2_ref = 0.0;
+  long nan_count = 0, inf_count = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (isnan(test[i])) { nan_count++; continue; }
+    if (isinf(test[i])) { inf_count++; continue; }
+    const double diff = fabsf(test[i] - ref[i]);
+    const double abs_ref = fabsf(ref[i]);
+    if (diff > max_abs) max_abs = diff;
+    if (abs_ref > 1e-10 && diff / abs_ref > max_rel) max_rel = diff / abs_ref;
+    l2_diff += diff * diff;
+    l2_ref += ref[i] * ref[i];
+  }
+  out->max_abs = max_abs;
+  out->max_rel = max_rel;
+  out->l2 = sqrt(l2_diff / (l2_ref + 1e-30));
+  out->nan_count = nan_count;
+  out->inf_count = inf_count;
+}
+
+// ---------------------------------------------------------------------------------
+// Convenience runners with the standard benchmark inputs (main.cpp:279-399).
+// ---------------------------------------------------------------------------------
+typedef int (*operator_fn)(FDTD_OPERATOR_ARGS);
+
+static int run_standard(operator_fn op, int NX, int NY, int NZ, int nt, int nsrc, float *u_out,
+                        float *max_abs_u, struct profiler *timers) {
+  if (NX <= 0 || NY <= 0 || NZ <= 0 || nt <= 0 || nsrc < 0) return (int)hipErrorInvalidValue;
+  const int nxp = NX + 2 * FDTD_HALO, nyp = NY + 2 * FDTD_HALO, nzp = NZ + 2 * FDTD_HALO;
+  const size_t volp = (size_t)nxp * nyp * nzp;
+  std::vector<float> u(3 * volp, 0.0f), m(volp, 1.5f);
+  std::vector<float> src((size_t)nt * (nsrc > 0 ? nsrc : 1)), coords((size_t)(nsrc > 0 ? nsrc : 1) * 3);
+  if (nsrc > 0) {
+    fdtd_fill_ricker(src.data(), nt, nsrc, 0.001f);
+    fdtd_fill_source_coords(coords.data(), nsrc, NX, NY, NZ);
+  }
+  int u_sizes[4] = {3, nxp, nyp, nzp}, m_sizes[3] = {nxp, nyp, nzp};
+  int src_sizes[2] = {nt, nsrc > 0 ? nsrc : 1}, coord_sizes[2] = {nsrc > 0 ? nsrc : 1, 3};
+  dataobj u_vec{}, m_vec{}, src_vec{}, coords_vec{};
+  u_vec.data = u.data(); u_vec.size = u_sizes; u_vec.nbytes = 3 * volp * sizeof(float);
+  m_vec.data = m.data(); m_vec.size = m_sizes; m_vec.nbytes = volp * sizeof(float);
+  src_vec.data = src.data(); src_vec.size = src_sizes; src_vec.nbytes = src.size() * sizeof(float);
+  coords_vec.data = coords.data(); coords_vec.size = coord_sizes; coords_vec.nbytes = coords.size() * sizeof(float);
+  profiler local{0.0, 0.0};
+  const int rc = op(&m_vec, &src_vec, &coords_vec, &u_vec, NX - 1, 0, NY - 1, 0, NZ - 1, 0, 0.001f,
+                    0.1f, 0.1f, 0.1f, 0.0f, 0.0f, 0.0f, nsrc > 0 ? nsrc - 1 : -1, 0, nt - 1, 0, 0, 1,
+                    timers ? timers : &local);
+  if (rc) return rc;
+  if (max_abs_u) {
+    float mx = 0.0f;
+    for (size_t i = 0; i < 3 * volp; ++i) mx = fmaxf(mx, fabsf(u[i]));
+    *max_abs_u = mx;
+  }
+  if (u_out) memcpy(u_out, u.data(), 3 * volp * sizeof(float));
+  return 0;
+}
+
+extern "C" int run_openacc(int NX, int NY, int NZ, int nt, int nsrc, float *u_out, float *max_abs_u,
+                           struct profiler *timers) {
+  return run_standard(Kernel_OpenACC, NX, NY, NZ, nt, nsrc, u_out, max_abs_u, timers);
+}
+extern "C" int run_cuda(int NX, int NY, int NZ, int nt, int nsrc, float *u_out, float *max_abs_u,
+                        struct profiler *timers) {
+  return run_standard(Kernel_CUDA, NX, NY, NZ, nt, nsrc, u_out, max_abs_u, timers);
+}
+extern "C" int run_cuda_optimized(int NX, int NY, int NZ, int nt, int nsrc, float *u_out,
+                                  float *max_abs_u, struct profiler *timers) {
+  return run_standard(Kernel_CUDA_Optimized, NX, NY, NZ, nt, nsrc, u_out, max_abs_u, timers);
+}

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the FDTD hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid n] [--variant v]
+
+One "step" is one time step of the propagator (section0 stencil sweep + section1 source
+scatter, reference openacc.cpp:148-205) on fields that are already resident in HBM.
+N = 1 runs BASELINE.json's headline configuration: 512^3 fp32, one Ricker source, the
+LDS-free x-marching kernel (Kernel_CUDA_Optimized's path).  With the defaults W = 5 and
+K = 45 the timed window is steps 5..49 of a 50-step run, i.e. exactly the reference's timer
+window (openacc.cpp:5,148).  N > 1 (launched by torch.distributed.run, one rank per GPU)
+runs the slab-decomposed propagator: every rank owns a 512-plane slab of a (512*N) x 512 x 512
+grid and exchanges 2 ghost planes per side and step with its neighbours over RCCL (weak
+scaling).  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+ALGO_BYTES_PER_CELL = 16.0     # read u[t0], u[t1], m; write u[t2]; 4 B each
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=45)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=512, help="cells per axis (per-rank slab thickness for N>1)")
+    ap.add_argument("--variant", default="auto", choices=["auto", "flat", "naive", "march", "tile3d"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="oracle steps for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, n, steps):
+    """Time the CPU oracle (test infrastructure; never on the product path) on a bounded sample
+    of the same workload: n^3, `steps` steps of the Ricker run, its own section timers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    u, m, src, coords = pkg.standard_inputs(n, n, n, steps, 1)
+    prof = ob.run_oracle(m, src, coords, u)
+    timed = steps - pkg.WARMUP_STEPS
+    secs = prof.section0 + prof.section1
+    return {
+        "value": round(n ** 3 * timed / secs / 1e6, 1),
+        "unit": "Mcells/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n}^3 fp32 Ricker run, {steps} steps, steps {pkg.WARMUP_STEPS}..{steps - 1} timed "
+                  f"({secs:.2f} s), OpenMP over x,y; bit-identical restatement of openacc.cpp:159-196",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    L = pkg.lib()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    n = args.grid
+    K, W = args.steps, args.warmup
+    total_steps = K + W
+    variant = pkg.VARIANTS[args.variant]
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from __graft_entry__ import load_package as _lp  # noqa: F401
+        slab = pkg.slab
+        prop = slab.SlabPropagator.standard_benchmark(n_per_rank=n, ny=n, nz=n, nt=total_steps,
+                                                     rank=rank, world=world, device=dev,
+                                                     variant=variant)
+        for t in range(W):
+            prop.step(t)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for t in range(W, total_steps):
+            prop.step(t)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kernel_ms = prop.mean_interior_kernel_ms()
+        cells_per_step = float(n) * n * n * world
+        launch_cells = prop.interior_cells()
+        dist.destroy_process_group()
+    else:
+        u, m, src, coords = pkg.standard_inputs(n, n, n, total_steps, 1)
+        u_d = torch.from_numpy(u).to(dev)
+        m_d = torch.from_numpy(m).to(dev)
+        s_d = torch.from_numpy(src).to(dev)
+        c_d = torch.from_numpy(coords).to(dev)
+        del u, m
+        npad = n + 2 * pkg.HALO
+        g = pkg.Geom(npad, npad, npad, 0, n - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+        stream = torch.cuda.current_stream()
+        sh = C.c_void_p(stream.cuda_stream)
+
+        def step(t):
+            t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
+            rc = L.fdtd_hip_stencil_step(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), t0, t1, t2, variant, sh)
+            assert rc == 0, rc
+            rc = L.fdtd_hip_source_inject(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(),
+                                          u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
+            assert rc == 0, rc
+
+        for t in range(W):
+            step(t)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for i, t in enumerate(range(W, total_steps)):
+            t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
+            ev[i][0].record(stream)
+            rc = L.fdtd_hip_stencil_step(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), t0, t1, t2, variant, sh)
+            ev[i][1].record(stream)
+            rc |= L.fdtd_hip_source_inject(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(),
+                                           u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        cells_per_step = float(n) ** 3
+        launch_cells = cells_per_step
+        max_u = float(u_d.abs().max().item())
+        assert np.isfinite(max_u) and max_u > 0.0, "field is empty or not finite"
+
+    if rank != 0:
+        return
+
+    mcells = cells_per_step * K / elapsed / 1e6
+    achieved = ALGO_BYTES_PER_CELL * launch_cells / (kernel_ms * 1e-3) / 1e9  # GB/s, dominant kernel
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath) and world == 1 and n == 512:
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mcells/s",
+        "value": round(mcells, 1),
+        "unit": "Mcells/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "achieved_hbm_GBps_whole_step": round(mcells * ALGO_BYTES_PER_CELL / 1e3, 1),
+        "config": {
+            "workload": (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
+                         f"{total_steps} steps ({W} untimed)" if world == 1 else
+                         f"{n * world}x{n}x{n} fp32 as {world} x-slabs of {n} planes, 2-plane ghost exchange "
+                         f"per step over RCCL, {total_steps} steps ({W} untimed)"),
+            "variant": args.variant,
+            "bytes_per_cell_update": ALGO_BYTES_PER_CELL,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "stencil sweep (section0)",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "avg_kernel_ms": round(kernel_ms, 4),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pkg, n, args.cpu_steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

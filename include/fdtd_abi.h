@@ -1,0 +1,207 @@
+/*
+ * fdtd_abi.h — C ABI of the MI355X (gfx950) 3D acoustic FDTD engine.
+ *
+ * Two layers are declared here, both plain C (pointers and sizes only):
+ *
+ *   1. The Devito-style operator ABI the reference driver binds
+ *      (reference main.cpp:35-50 for the structs, main.cpp:53-72 for the three
+ *      24-argument operators).  A program written against the reference links
+ *      against libfdtd_hip.so without source changes.
+ *
+ *   2. A device-resident ABI (fdtd_hip_*): the same two device kernels the
+ *      reference launches per time step (cuda.cu:61-108 and cuda.cu:112-170 /
+ *      cuda_optimized.cu:63-260), callable on fields that already live in HBM.
+ *      The operators of layer 1 are built on it; callers that keep the wavefield on
+ *      the GPU between steps (the benchmark, the multi-GPU slab propagator) use it
+ *      directly.
+ *
+ * Memory layout (identical on host and device, reference cuda.cu:38-42):
+ *   u[t][x][y][z]  float32, t in 0..2, z contiguous; every spatial axis is padded
+ *   by FDTD_HALO cells on both sides, i.e. interior cell i lives at padded index
+ *   i + FDTD_HALO (openacc.cpp:102).  m[x][y][z] has the same padded shape.
+ *   src[time][p], src_coords[p][3].
+ */
+#ifndef FDTD_ABI_H
+#define FDTD_ABI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Space order 4: radius-2 star stencil, padding of 4 cells per side
+ * (main.cpp:27-32, cuda.cu:55). */
+#define FDTD_STENCIL_ORDER 4
+#define FDTD_RADIUS 2
+#define FDTD_HALO 4
+/* The first FDTD_WARMUP_STEPS time steps of a call are real steps that are not
+ * timed (openacc.cpp:5,90-93; cuda.cu:56,232). */
+#define FDTD_WARMUP_STEPS 5
+
+/* main.cpp:35-45.  Only data, size and nbytes are ever populated by the driver
+ * (main.cpp:114-126, 540-545); the remaining fields are carried for layout
+ * compatibility (72 bytes on LP64). */
+struct dataobj {
+  void *data;
+  int *size;
+  unsigned long nbytes;
+  unsigned long *npsize;
+  unsigned long *dsize;
+  int *hsize;
+  int *hofs;
+  int *oofs;
+  void *dmap;
+};
+
+/* main.cpp:47-50.  Seconds spent in the stencil (section0) and in the source
+ * injection (section1) over time steps time_m+FDTD_WARMUP_STEPS .. time_M. */
+struct profiler {
+  double section0;
+  double section1;
+};
+
+/* ---------------------------------------------------------------------------
+ * Layer 1: operator ABI (main.cpp:53-72).  Max comes before min in every pair;
+ * all ranges are inclusive.  Host buffers in, host buffers out: u_vec->data is
+ * updated in place (all three time levels, halos included), m/src/src_coords are
+ * read-only.  Returns 0 on success, a positive hipError_t value on failure
+ * (cuda.cu:280-284; hipErrorInvalidValue for inconsistent shapes,
+ * cuda_optimized.cu:346-347).  Timers are accumulated (+=) like openacc.cpp:3 and
+ * cuda.cu:11-16, so the caller zeroes them (main.cpp:390).
+ *
+ *   Kernel_OpenACC        replaces openacc.cpp:61-216  (flat collapse(3) sweep, the
+ *                         shape an OpenACC compiler gives the loop nest)
+ *   Kernel_CUDA           replaces cuda.cu:173-323     (one thread per cell, global
+ *                         memory only, z on the lanes)
+ *   Kernel_CUDA_Optimized replaces cuda_optimized.cu:282-514 (LDS-staged x-marching
+ *                         tile kernel; the default fast path)
+ * ------------------------------------------------------------------------- */
+#define FDTD_OPERATOR_ARGS                                                        \
+  struct dataobj *m_vec, struct dataobj *src_vec, struct dataobj *src_coords_vec, \
+      struct dataobj *u_vec, const int x_M, const int x_m, const int y_M,         \
+      const int y_m, const int z_M, const int z_m, const float dt,                \
+      const float h_x, const float h_y, const float h_z, const float o_x,         \
+      const float o_y, const float o_z, const int p_src_M, const int p_src_m,     \
+      const int time_M, const int time_m, const int deviceid, const int devicerm, \
+      struct profiler *timers
+
+int Kernel_OpenACC(FDTD_OPERATOR_ARGS);
+int Kernel_CUDA(FDTD_OPERATOR_ARGS);
+int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS);
+
+/* Same operator with the three wavefield levels stored as IEEE binary16 in HBM and
+ * all arithmetic in fp32 (the reference's USE_FP32_ONLY=0 build,
+ * cuda_optimized.cu:59-61,261-279,482-499).  Host buffers stay fp32. */
+int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS);
+
+/* Optional hook the reference driver looks up as a weak symbol and calls once per
+ * benchmark sweep (main.cpp:84,266-276).  t_fuse/nfields/use_tc select nothing in
+ * this engine (no tensor-core path exists for a 13-point star); the call records the
+ * values and returns. */
+void FDTD_SetRuntimeConfig(int use_tc, int t_fuse, int nfields);
+
+/* ---------------------------------------------------------------------------
+ * Layer 2: device-resident ABI.  All pointers are device pointers; `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+ * with respect to the host.  Return value: 0 or a positive hipError_t.
+ * ------------------------------------------------------------------------- */
+
+/* Stencil variants selectable at run time. */
+enum fdtd_variant {
+  FDTD_VARIANT_FLAT = 0,     /* flat collapse(3) index, one cell per thread        */
+  FDTD_VARIANT_NAIVE = 1,    /* 3-D grid, z on lanes, global loads only (cuda.cu)   */
+  FDTD_VARIANT_MARCH = 2,    /* x-marching, register column + LDS centre plane      */
+  FDTD_VARIANT_TILE3D = 3,   /* 8x8x8 outputs from a 12x12x12 LDS tile              */
+  FDTD_VARIANT_AUTO = -1     /* MARCH when the shape allows it, else NAIVE          */
+};
+
+/* Geometry of one padded field set; passed by pointer. */
+struct fdtd_geom {
+  int nxp, nyp, nzp;          /* padded extents (u_vec->size[1..3])                 */
+  int x_m, x_M, y_m, y_M, z_m, z_M; /* inclusive interior ranges to update         */
+  float dt, h_x, h_y, h_z;    /* time step and grid spacings                        */
+  float o_x, o_y, o_z;        /* grid origin                                        */
+};
+
+/* One leapfrog update  u[t2] <- stencil(u[t0], u[t1], m)  over the ranges in g.
+ * Replaces one launch of stencil_update_kernel_1step (cuda.cu:237-243) /
+ * stencil_update_h100_scalar_pipelined_kernel (cuda_optimized.cu:404-416).
+ * t0/t1/t2 are the ring indices (time%3, (time+2)%3, (time+1)%3; openacc.cpp:148).
+ * u points at level 0 of the [3][nxp][nyp][nzp] array. */
+int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, float *u,
+                          int t0, int t1, int t2, int variant, void *stream);
+
+/* Trilinear 8-corner scatter of sources p_src_m..p_src_M at time index `time` into
+ * u[t2].  Replaces one launch of source_inject_kernel (cuda.cu:253-261).
+ * src is [*][src_stride], src_coords is [*][coord_stride]. */
+int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m,
+                           const float *src, const float *src_coords, float *u,
+                           int t2, int time, int p_src_m, int p_src_M,
+                           int src_stride, int coord_stride, void *stream);
+
+/* The whole time loop on device-resident fields: steps time_m..time_M, ring
+ * indexing and section timers exactly as the operators do (timers may be NULL, in
+ * which case nothing is timed and no host synchronisation happens before return
+ * other than the final stream synchronise).  This is the body of every Kernel_*
+ * operator between its host-to-device and device-to-host copies
+ * (cuda.cu:232-314). */
+int fdtd_hip_time_loop(const struct fdtd_geom *g, const float *m, const float *src,
+                       const float *src_coords, float *u, int p_src_m, int p_src_M,
+                       int src_stride, int coord_stride, int time_m, int time_M,
+                       int variant, void *stream, struct profiler *timers);
+
+/* fp16-storage counterparts (u is __half[3][nxp][nyp][nzp]; m, src stay fp32). */
+int fdtd_hip_stencil_step_h16(const struct fdtd_geom *g, const float *m, void *u_h16,
+                              int t0, int t1, int t2, void *stream);
+int fdtd_hip_source_inject_h16(const struct fdtd_geom *g, const float *m,
+                               const float *src, const float *src_coords,
+                               void *u_h16, int t2, int time, int p_src_m,
+                               int p_src_M, int src_stride, int coord_stride,
+                               void *stream);
+int fdtd_hip_convert_f32_to_h16(const float *in, void *out_h16, size_t n, void *stream);
+int fdtd_hip_convert_h16_to_f32(const void *in_h16, float *out, size_t n, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Host-side input generators and parity metrics of the reference driver, restated
+ * so that a caller can reproduce its runs without the driver.
+ * ------------------------------------------------------------------------- */
+
+/* main.cpp:290-298: src[t*S+s] = (1-2a)exp(-a), a = pi^2 f0^2 (t*dt - 1/f0)^2,
+ * f0 = 10, all in float. */
+void fdtd_fill_ricker(float *src, int T, int S, float dt);
+/* main.cpp:301-325: the first S of the 27 tick combinations {1/4,1/2,3/4}*(n-1)*0.1
+ * per axis (x-major), then the grid centre for any further sources. */
+void fdtd_fill_source_coords(float *coords, int S, int nx, int ny, int nz);
+/* main.cpp:525-532: level0 = level1 = sin(i*0.001f)*10+100 over all padded cells,
+ * level2 = 0, m = 1.5.  u has 3*volp floats, m has volp floats. */
+void fdtd_fill_correctness_inputs(float *u, float *m, size_t volp);
+
+/* main.cpp:573-593: NaN/Inf in `test` are counted and skipped; the rest feed
+ * max_abs, max_rel (where |ref| > 1e-10) and L2 = sqrt(sum d^2/(sum ref^2+1e-30)). */
+struct fdtd_parity {
+  double max_abs, max_rel, l2;
+  long nan_count, inf_count;
+};
+void fdtd_compare_fields(const float *test, const float *ref, size_t n,
+                         struct fdtd_parity *out);
+
+/* Convenience runners with the standard benchmark inputs of main.cpp:279-399
+ * (m = 1.5, u = 0, h = 0.1, dt = 1e-3, origin 0, nsrc Ricker sources, time 0..nt-1).
+ * They allocate and fill host buffers, call the matching Kernel_* operator, report
+ * max|u| over the three levels and the timers, and free everything.
+ * u_out may be NULL; if not it receives 3*(NX+8)*(NY+8)*(NZ+8) floats. */
+int run_openacc(int NX, int NY, int NZ, int nt, int nsrc, float *u_out,
+                float *max_abs_u, struct profiler *timers);
+int run_cuda(int NX, int NY, int NZ, int nt, int nsrc, float *u_out,
+             float *max_abs_u, struct profiler *timers);
+int run_cuda_optimized(int NX, int NY, int NZ, int nt, int nsrc, float *u_out,
+                       float *max_abs_u, struct profiler *timers);
+
+/* Version string of the library ("fdtd-hip gfx950 <variant list>"). */
+const char *fdtd_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTD_ABI_H */

@@ -1,0 +1,205 @@
+/*
+ * fdtd_oracle.c — CPU restatement of the reference's OpenACC operator.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check and the
+ * benchmark's cpu_baseline leg load this library; the shipped engine
+ * (libfdtd_hip.so) never calls into it and has no CPU fallback.
+ *
+ * What it restates (all citations are into the reference tree):
+ *   openacc.cpp:84-87    r1 = 1/dt^2, r2..r4 = 1/h^2, computed in float on the host
+ *   openacc.cpp:90-93    ring indices t0 = time%3, t1 = (time+2)%3, t2 = (time+1)%3
+ *   openacc.cpp:90-145   the first 5 steps are real but untimed
+ *   openacc.cpp:159-164  13-point star Laplacian + leapfrog update ("section0")
+ *   openacc.cpp:173      guard of the source section
+ *   openacc.cpp:185-196  trilinear 8-corner source scatter ("section1")
+ *
+ * Arithmetic contract: every operation is an IEEE-754 binary32 operation in the
+ * order and association of the reference expression; build with -ffp-contract=off
+ * and without -ffast-math so that no FMA contraction or re-association happens.
+ * Under that contract a serial run is bit-identical to the reference translation
+ * unit compiled with g++ -O2 (checked by tests/test_oracle_vs_reference.py when the
+ * reference build under oracle/_ref/ is present).
+ *
+ * Pinning: the reference ships no golden vectors for this path.  The restatement is
+ * pinned by (a) bit-comparison with the compiled reference (oracle/_ref, built by
+ * oracle/build_ref.sh from the sources where they lie) and (b) the fixtures under
+ * tests/golden/ generated from that compiled reference by
+ * tests/golden/make_golden.py.
+ *
+ * The x loop is parallelised with OpenMP when built with -fopenmp.  Cells of one
+ * sweep are independent (reads from levels t0/t1, writes to level t2), so the
+ * thread count does not change any bit of the result.  The source scatter stays
+ * serial: it is O(8*nsrc) and its += order (p_src outermost, then x, y, z corner)
+ * is the order a serial run of the reference uses.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <math.h>
+#include <stddef.h>
+#include <sys/time.h>
+
+#include "../include/fdtd_abi.h"
+
+static double now_s(void) {
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return (double)tv.tv_sec + (double)tv.tv_usec / 1000000.0;
+}
+
+/* openacc.cpp:159-164.  One interior sweep: u[t2] <- f(u[t0], u[t1], m). */
+static void oracle_section0(const float *restrict m, const float *restrict u0,
+                            const float *restrict u1, float *restrict u2,
+                            long nyp, long nzp, int x_m, int x_M, int y_m, int y_M,
+                            int z_m, int z_M, float dt, float r1, float r2,
+                            float r3, float r4) {
+  const long sx = nyp * nzp; /* stride of one x step */
+  const long sy = nzp;       /* stride of one y step */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int x = x_m; x <= x_M; x += 1) {
+    for (int y = y_m; y <= y_M; y += 1) {
+      const long row = (long)(x + 4) * sx + (long)(y + 4) * sy + 4;
+      for (int z = z_m; z <= z_M; z += 1) {
+        const long c = row + z;
+        const float uc = u0[c];
+        const float r5 = -2.50F * uc;
+        const float dxx = r5 + (-8.33333333e-2F) * (u0[c - 2 * sx] + u0[c + 2 * sx]) +
+                          1.333333330F * (u0[c - sx] + u0[c + sx]);
+        const float dyy = r5 + (-8.33333333e-2F) * (u0[c - 2 * sy] + u0[c + 2 * sy]) +
+                          1.333333330F * (u0[c - sy] + u0[c + sy]);
+        const float dzz = r5 + (-8.33333333e-2F) * (u0[c - 2] + u0[c + 2]) +
+                          1.333333330F * (u0[c - 1] + u0[c + 1]);
+        const float mc = m[c];
+        u2[c] = dt * dt *
+                (r2 * dxx + r3 * dyy + r4 * dzz - (-2.0F * r1 * uc + r1 * u1[c]) * mc) /
+                mc;
+      }
+    }
+  }
+}
+
+/* openacc.cpp:185-196.  Serial, in the loop order of the reference. */
+static void oracle_section1(const float *restrict m, const float *restrict src,
+                            const float *restrict coords, float *restrict u2,
+                            long nyp, long nzp, int x_m, int x_M, int y_m, int y_M,
+                            int z_m, int z_M, float h_x, float h_y, float h_z,
+                            float o_x, float o_y, float o_z, int p_src_m,
+                            int p_src_M, int time, long src_stride,
+                            long coord_stride) {
+  const long sx = nyp * nzp, sy = nzp;
+  for (int p = p_src_m; p <= p_src_M; p += 1) {
+    for (int rx = 0; rx <= 1; rx += 1) {
+      for (int ry = 0; ry <= 1; ry += 1) {
+        for (int rz = 0; rz <= 1; rz += 1) {
+          const float gx = (-o_x + coords[p * coord_stride + 0]) / h_x;
+          const float gy = (-o_y + coords[p * coord_stride + 1]) / h_y;
+          const float gz = (-o_z + coords[p * coord_stride + 2]) / h_z;
+          const int posx = (int)floorf(gx);
+          const int posy = (int)floorf(gy);
+          const int posz = (int)floorf(gz);
+          const float px = -floorf(gx) + gx;
+          const float py = -floorf(gy) + gy;
+          const float pz = -floorf(gz) + gz;
+          if (rx + posx >= x_m - 1 && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
+              rx + posx <= x_M + 1 && ry + posy <= y_M + 1 && rz + posz <= z_M + 1) {
+            const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) *
+                             (ry * py + (1 - ry) * (1 - py)) *
+                             (rz * pz + (1 - rz) * (1 - pz)) *
+                             src[(long)time * src_stride + p] /
+                             m[(long)(posx + 4) * sx + (long)(posy + 4) * sy + (posz + 4)];
+            u2[(long)(rx + posx + 4) * sx + (long)(ry + posy + 4) * sy +
+               (rz + posz + 4)] += r0;
+          }
+        }
+      }
+    }
+  }
+}
+
+/* The operator, same signature and semantics as Kernel_OpenACC (openacc.cpp:61). */
+int Oracle_Kernel_OpenACC(FDTD_OPERATOR_ARGS) {
+  (void)deviceid;
+  (void)devicerm;
+  const long nxp = u_vec->size[1], nyp = u_vec->size[2], nzp = u_vec->size[3];
+  const long vol = nxp * nyp * nzp;
+  float *u = (float *)u_vec->data;
+  const float *m = (const float *)m_vec->data;
+  const float *src = (const float *)src_vec->data;
+  const float *coords = (const float *)src_coords_vec->data;
+  const long src_stride = src_vec->size[1];
+  const long coord_stride = src_coords_vec->size[1];
+
+  const float r1 = 1.0F / (dt * dt);
+  const float r2 = 1.0F / (h_x * h_x);
+  const float r3 = 1.0F / (h_y * h_y);
+  const float r4 = 1.0F / (h_z * h_z);
+  const int has_src =
+      (src_vec->size[0] * src_vec->size[1] > 0 && p_src_M - p_src_m + 1 > 0);
+
+  for (int time = time_m; time <= time_M; time += 1) {
+    const int t0 = time % 3, t1 = (time + 2) % 3, t2 = (time + 1) % 3;
+    const int timed = (time >= time_m + FDTD_WARMUP_STEPS) && timers;
+    double a = timed ? now_s() : 0.0;
+    oracle_section0(m, u + t0 * vol, u + t1 * vol, u + t2 * vol, nyp, nzp, x_m, x_M,
+                    y_m, y_M, z_m, z_M, dt, r1, r2, r3, r4);
+    double b = timed ? now_s() : 0.0;
+    if (has_src)
+      oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
+                      z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time,
+                      src_stride, coord_stride);
+    if (timed) {
+      double c = now_s();
+      timers->section0 += b - a;
+      timers->section1 += c - b;
+    }
+  }
+  return 0;
+}
+
+/* Single sweeps on caller-chosen levels; used by the slab-decomposition tests, which
+ * need a stepper that can be driven one time step at a time. */
+void oracle_stencil_step(const float *m, float *u, long nxp, long nyp, long nzp,
+                         int x_m, int x_M, int y_m, int y_M, int z_m, int z_M,
+                         float dt, float h_x, float h_y, float h_z, int t0, int t1,
+                         int t2) {
+  const long vol = nxp * nyp * nzp;
+  const float r1 = 1.0F / (dt * dt);
+  const float r2 = 1.0F / (h_x * h_x);
+  const float r3 = 1.0F / (h_y * h_y);
+  const float r4 = 1.0F / (h_z * h_z);
+  oracle_section0(m, u + t0 * vol, u + t1 * vol, u + t2 * vol, nyp, nzp, x_m, x_M,
+                  y_m, y_M, z_m, z_M, dt, r1, r2, r3, r4);
+}
+
+void oracle_source_inject(const float *m, const float *src, const float *coords,
+                          float *u, long nxp, long nyp, long nzp, int x_m, int x_M,
+                          int y_m, int y_M, int z_m, int z_M, float h_x, float h_y,
+                          float h_z, float o_x, float o_y, float o_z, int p_src_m,
+                          int p_src_M, int time, long src_stride, long coord_stride,
+                          int t2) {
+  const long vol = nxp * nyp * nzp;
+  oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
+                  z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time,
+                  src_stride, coord_stride);
+}
+
+/* main.cpp:573-593, the driver's parity metrics, restated independently of the
+ * product's own copy so the two can be checked against each other. */
+void oracle_compare_fields(const float *test, const float *ref, size_t n,
+                           struct fdtd_parity *out) {
+  double max_abs = 0.0, max_rel = 0.0, l2d = 0.0, l2r = 0.0;
+  long nan_count = 0, inf_count = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (isnan(test[i])) { nan_count++; continue; }
+    if (isinf(test[i])) { inf_count++; continue; }
+    const double diff = fabs((double)(test[i] - ref[i]));
+    const double abs_ref = fabs((double)ref[i]);
+    if (diff > max_abs) max_abs = diff;
+    if (abs_ref > 1e-10 && diff / abs_ref > max_rel) max_rel = diff / abs_ref;
+    l2d += diff * diff;
+    l2r += (double)(ref[i] * ref[i]);
+  }
+  out->max_abs = max_abs;
+  out->max_rel = max_rel;
+  out->l2 = sqrt(l2d / (l2r + 1e-30));
+  out->nan_count = nan_count;
+  out->inf_count = inf_count;
+}

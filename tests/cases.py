@@ -1,0 +1,100 @@
+"""Parity cases shared by the fixture generator and the tests.
+
+Each case builds its inputs deterministically (no reference code involved): the driver's own
+generators for the two published input sets (main.cpp:285-356 and 525-532), seeded numpy
+for the edge cases the reference never exercises.  `build(case, pkg)` returns a dict with the
+arrays and the keyword arguments of pkg.run_operator.
+"""
+import zlib
+
+import numpy as np
+
+HALO = 4
+
+
+def _rng_field(rng, shape, lo, hi):
+    return rng.uniform(lo, hi, size=shape).astype(np.float32)
+
+
+CASES = {
+    # name: (kind, params)
+    "ricker_n32": ("ricker", dict(n=(32, 32, 32), nt=50, nsrc=1)),
+    "ricker_n64": ("ricker", dict(n=(64, 64, 64), nt=50, nsrc=1)),
+    "correctness_n32": ("correctness", dict(n=32, nt=50)),
+    "correctness_n64": ("correctness", dict(n=64, nt=50)),
+    "ricker27_n32": ("ricker", dict(n=(32, 32, 32), nt=20, nsrc=27)),
+    # 30 sources: 27 ticks + 3 copies of the grid centre, i.e. coincident scatter targets
+    "ricker30_n24_overlap": ("ricker", dict(n=(24, 24, 24), nt=12, nsrc=30)),
+    "noncubic_aniso": ("random", dict(n=(20, 36, 44), nt=12, nsrc=2, h=(0.8, 1.0, 1.25), seed=11,
+                                      edge_source=True)),
+    "odd_sizes": ("random", dict(n=(17, 33, 65), nt=9, nsrc=3, h=(1.0, 1.0, 1.0), seed=12)),
+    "tile_edges_100": ("random", dict(n=(12, 100, 260), nt=7, nsrc=1, h=(1.0, 0.9, 1.1), seed=13)),
+    "subrange_aligned": ("random", dict(n=(32, 32, 32), nt=10, nsrc=2, h=(1.0, 1.0, 1.0), seed=14,
+                                        bounds=(3, 20, 2, 29, 4, 27))),
+    "subrange_unaligned": ("random", dict(n=(32, 32, 32), nt=10, nsrc=2, h=(1.0, 1.0, 1.0), seed=15,
+                                          bounds=(1, 30, 5, 26, 5, 26))),
+    "time_offset": ("random", dict(n=(24, 24, 24), nt=19, nsrc=2, h=(1.0, 1.0, 1.0), seed=16,
+                                   time_m=7)),
+    "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
+    "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
+}
+
+# cases whose scatter targets coincide: float atomics may land in any order on the GPU
+ORDER_DEPENDENT = {"ricker30_n24_overlap"}
+
+
+def build(name, pkg):
+    kind, p = CASES[name]
+    if kind == "ricker":
+        nx, ny, nz = p["n"]
+        u, m, src, coords = pkg.standard_inputs(nx, ny, nz, p["nt"], p["nsrc"])
+        return dict(u=u, m=m, src=src, coords=coords, kw=dict())
+    if kind == "correctness":
+        u, m = pkg.fill_correctness_inputs(p["n"])
+        return dict(u=u, m=m, src=None, coords=None,
+                    kw=dict(time_M=p["nt"] - 1, h=(1.0, 1.0, 1.0)))
+    # random: smooth-ish random wavefield on levels 0 and 1 (halos included), varying m
+    rng = np.random.default_rng(p["seed"])
+    nx, ny, nz = p["n"]
+    shape = (nx + 2 * HALO, ny + 2 * HALO, nz + 2 * HALO)
+    u = np.zeros((3,) + shape, dtype=np.float32)
+    u[0] = _rng_field(rng, shape, -1.0, 1.0)
+    u[1] = u[0] + _rng_field(rng, shape, -0.01, 0.01)
+    u[2] = _rng_field(rng, shape, -1.0, 1.0)  # stale data in the level that gets overwritten
+    m = _rng_field(rng, shape, 1.0, 3.0)
+    h = p["h"]
+    nt, nsrc = p["nt"], p["nsrc"]
+    kw = dict(h=h, dt=1e-3)
+    if "bounds" in p:
+        kw["bounds"] = p["bounds"]
+    if "time_m" in p:
+        kw["time_m"] = p["time_m"]
+    src = coords = None
+    if nsrc > 0:
+        src = _rng_field(rng, (nt, nsrc), -50.0, 50.0)
+        ext = np.array([nx - 1, ny - 1, nz - 1], dtype=np.float64) * np.array(h)
+        coords = (rng.uniform(0.05, 0.95, size=(nsrc, 3)) * ext).astype(np.float32)
+        if p.get("edge_source"):
+            # a source in the outermost cell: its scatter reaches the first halo layer
+            coords[0] = np.array([(nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2]],
+                                 dtype=np.float32)
+        kw["time_M"] = nt - 1
+    else:
+        kw["time_M"] = nt - 1
+    return dict(u=u, m=m, src=src, coords=coords, kw=kw)
+
+
+def digest(u):
+    """Bit-level digest of a wavefield: CRC32 of each level + fp64 moments."""
+    u = np.ascontiguousarray(u)
+    d = {"crc32": [format(zlib.crc32(u[t].tobytes()), "08x") for t in range(3)]}
+    f = u.astype(np.float64)
+    d["sum"] = float(f.sum())
+    d["sumsq"] = float((f * f).sum())
+    d["maxabs"] = float(np.abs(f).max())
+    return d
+
+
+def sample_indices(size, count=4096, seed=1234):
+    rng = np.random.default_rng(seed)
+    return np.sort(rng.choice(size, size=min(count, size), replace=False))

@@ -1,0 +1,111 @@
+"""CPU tests of the boundary: the library loads, exports every symbol the header declares,
+keeps the reference's struct layout, and its host-side helpers (input generators, parity
+metrics, argument checks) behave like the reference driver's.  No GPU compute is called."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fdtd_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:int|void|const char \*)\s*\**\s*([A-Za-z_]\w*)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported(hiplib):
+    names = declared_symbols()
+    for must in ("Kernel_OpenACC", "Kernel_CUDA", "Kernel_CUDA_Optimized", "fdtd_hip_stencil_step",
+                 "fdtd_hip_source_inject", "fdtd_hip_time_loop", "run_cuda_optimized",
+                 "FDTD_SetRuntimeConfig"):
+        assert must in names
+    for n in names:
+        assert hasattr(hiplib, n), f"libfdtd_hip.so does not export {n}"
+
+
+def test_struct_layout_matches_reference(pkg):
+    # main.cpp:35-50: nine pointer-sized fields, two doubles
+    assert C.sizeof(pkg.Dataobj) == 72
+    assert pkg.Dataobj.data.offset == 0 and pkg.Dataobj.size.offset == 8 and pkg.Dataobj.nbytes.offset == 16
+    assert C.sizeof(pkg.Profiler) == 16
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    monkeypatch.setattr(pkg.abi, "_lib", None)
+    monkeypatch.setattr(pkg.abi, "lib_path", lambda: "/nonexistent/libfdtd_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.abi.lib()
+
+
+def test_ricker_generator(pkg):
+    src = pkg.fill_ricker(50, 3)
+    assert src.shape == (50, 3) and (src[:, 0] == src[:, 2]).all()
+    f0, dt = np.float32(10.0), np.float32(1e-3)
+    for t in (0, 7, 49):
+        ts = np.float32(np.float32(t) * dt) - np.float32(1.0) / f0
+        a = np.float32(math.pi) * np.float32(math.pi) * f0 * f0 * ts * ts
+        want = (1.0 - 2.0 * float(a)) * math.exp(-float(a))
+        assert float(src[t, 0]) == pytest.approx(want, rel=2e-6)
+
+
+def test_source_coords_generator(pkg):
+    n = 32
+    c = pkg.fill_source_coords(30, n, n, n)
+    L = np.float32(n - 1) * np.float32(0.1)
+    assert np.allclose(c[0], [0.25 * L] * 3, rtol=1e-6)
+    assert np.allclose(c[1], [0.25 * L, 0.25 * L, 0.5 * L], rtol=1e-6)   # z varies fastest
+    assert np.allclose(c[26], [0.75 * L] * 3, rtol=1e-6)
+    assert np.allclose(c[27:], 0.5 * L, rtol=1e-6)                        # extras at the centre
+    # the benchmark source sits at grid coordinate 0.25*(n-1) = 7.75
+    assert np.float32(c[0, 0]) / np.float32(0.1) == pytest.approx(7.75, rel=1e-6)
+
+
+def test_correctness_inputs(pkg):
+    u, m = pkg.fill_correctness_inputs(8)
+    assert (m == 1.5).all() and (u[2] == 0).all() and np.array_equal(u[0], u[1])
+    flat = u[0].reshape(-1)
+    for i in (0, 5, 4095):
+        want = math.sin(float(np.float32(np.float32(i) * np.float32(0.001)))) * 10.0 + 100.0
+        assert float(flat[i]) == pytest.approx(want, rel=1e-6)
+
+
+def test_parity_metrics_match_oracle_copy(pkg):
+    rng = np.random.default_rng(5)
+    ref = rng.normal(size=10000).astype(np.float32) * 100
+    test = ref + rng.normal(size=10000).astype(np.float32) * 1e-3
+    test[17] = np.nan
+    test[99] = np.inf
+    ref[5] = 0.0
+    a = pkg.compare_fields(test, ref)
+    b = pkg.Parity()
+    ob.oracle().oracle_compare_fields(test.ctypes.data, ref.ctypes.data, test.size, C.byref(b))
+    assert (a.max_abs, a.max_rel, a.l2, a.nan_count, a.inf_count) == \
+           (b.max_abs, b.max_rel, b.l2, b.nan_count, b.inf_count)
+    assert a.nan_count == 1 and a.inf_count == 1
+    ok = np.isfinite(test)
+    d = np.abs(test[ok] - ref[ok]).astype(np.float64)
+    assert a.max_abs == pytest.approx(d.max())
+    assert a.l2 == pytest.approx(np.sqrt((d ** 2).sum() / ((ref[ok].astype(np.float64) ** 2).sum() + 1e-30)), rel=1e-6)
+
+
+def test_operator_rejects_bad_shapes_before_touching_the_gpu(pkg, hiplib):
+    """Shape errors return hipErrorInvalidValue (1), like cuda_optimized.cu:346-347."""
+    u = np.zeros((3, 12, 12, 12), np.float32)
+    m_bad = np.zeros((12, 12, 11), np.float32)
+    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m_bad, None, None, u, time_M=3)
+    assert rc == 1
+    u2 = np.zeros((2, 12, 12, 12), np.float32)
+    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA, np.zeros((12, 12, 12), np.float32), None, None, u2, time_M=3)
+    assert rc == 1
+    # sources requested but no source table
+    m = np.ones((12, 12, 12), np.float32)
+    rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, None, None, u, time_M=3, p_src=(0, 0))
+    assert rc == 1
