@@ -10,7 +10,7 @@ import numpy as np
 
 HALO = 4            # main.cpp:32, cuda.cu:55
 WARMUP_STEPS = 5    # openacc.cpp:5
-VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "auto": -1}
+VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "auto": -1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -67,6 +67,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime.  If it is going to be used in this process (device
+    # memory, streams, torch.distributed) it has to be loaded before libfdtd_hip.so pulls in the
+    # system one, otherwise torch finds the GPU already claimed by a second runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(

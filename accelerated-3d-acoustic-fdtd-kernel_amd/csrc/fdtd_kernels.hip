@@ -98,27 +98,19 @@ __global__ __launch_bounds__(256) void stencil_naive_kernel(StencilArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// MARCH: the fast path.
+// Building blocks of the marching kernel.
 //
-// A wave owns a tile of RY rows (y) by 256 cells (z, one float4 per lane) and marches
-// along x.  Everything it needs lives in its own registers:
-//   * the x-neighbours: a 5-plane register column (x-2..x+2) per owned row;
-//   * the y-neighbours: the centre plane of the 2 rows above and below the tile is
-//     loaded too, so rows y-2..y+RY+1 of the centre plane are all register resident;
+// A wave owns RY rows (y) by 256 cells (z, one float4 per lane) and marches along x:
+//   * the x-neighbours live in a register column (planes x-2..x+2 of each owned row);
 //   * the z-neighbours: lanes hold consecutive float4s, so z-2,z-1 / z+4,z+5 are the
-//     .z,.w / .x,.y of the previous / next lane, fetched with DPP wavefront shifts;
-//     the first and last lane take them from an 8-byte edge load instead (it rides
-//     in the `old` operand of the DPP move, which is what an unsourced lane keeps).
-// There is no LDS and no barrier: each wave runs its own software pipeline, issuing
-// the loads of iteration x+1 (u0 plane x+3 of its rows, halo rows and edges of plane
-// x+1, u1 and m of plane x+1) before it computes plane x, so about 5 KB per owned row
-// are in flight per wave at all times.
-//
+//     .z,.w / .x,.y of the previous / next lane, fetched with DPP wavefront shifts; the
+//     first and last lane take them from an 8-byte edge load instead (it rides in the
+//     `old` operand of the DPP move, which is what an unsourced lane keeps);
+//   * the y-neighbours come from the other waves of the workgroup through LDS.
 // Requirements checked by the launcher: nzp % 4 == 0, z_m % 4 == 0, extent in z a
 // multiple of 4, 16-byte aligned level pointers, and z_M + 8 <= nzp - 1 so that the
 // float4 behind the last owned one is inside the row.
 // ---------------------------------------------------------------------------------
-constexpr int MARCH_WAVES = 4;  // waves per workgroup (independent; grouped for locality)
 
 __device__ __forceinline__ float dpp_from_prev_lane(float edge, float v) {
   // lane i <- lane i-1; lane 0 keeps `edge`
@@ -140,110 +132,164 @@ __device__ __forceinline__ int xcd_contiguous_tile(int b, int nblocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld_stream(const float *p) {
+  if (NT) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const float4 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st_stream(float *p, float4 v) {
+  if (NT) {
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4 *>(p));
+  } else {
+    *reinterpret_cast<float4 *>(p) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// MARCH + LDS row exchange (the default fast path).
+//
+// Same register column along x as above, but the NW waves of a workgroup are stacked
+// in y and hand each other the centre plane of their rows through LDS, so only the 4
+// rows outside the NW*RY-row workgroup tile are fetched a second time (and those hit
+// in L2 when the neighbouring workgroup marches in step).  One workgroup barrier per
+// plane; the LDS plane is double buffered.
+//
+// Software pipeline.  gfx950 retires vector loads and stores through one in-order
+// counter, so a wait for a load also waits for every older store.  The loop is
+// therefore arranged so that nothing ever has to wait for the youngest operations:
+//   * an iteration first issues every load the NEXT iteration needs (u0 plane x+3 of
+//     the owned rows; u1, m, z-edges and the outside row of plane x+1) into one of two
+//     register sets, then computes plane x from the other set, then stores;
+//   * the two sets alternate by unrolling the loop twice (no register copies of
+//     freshly loaded data), and the only copies are the 4 older planes of the column;
+//   * no vector-memory instruction sits under a divergent branch (edge loads are
+//     issued by every lane, full tiles store unconditionally), so the compiler's
+//     counted waits are exact and the stores of plane x stay in flight while plane
+//     x+1 is computed.
+// Addresses are a wave-uniform plane pointer (scalar registers) plus one 32-bit lane
+// offset per row.
+// ---------------------------------------------------------------------------------
 template <int RY>
-__global__ __launch_bounds__(MARCH_WAVES * 64) void stencil_march_kernel(StencilArgs a, int xchunk,
-                                                                         int nzt, int nyt) {
+struct MarchSet {
+  float4 col[RY];   // u0, plane x+2 relative to the plane this set is "current" for
+  float4 prev[RY];  // u1 of the current plane
+  float4 med[RY];   // m of the current plane
+  float2 edge[RY];  // z-edge cells of the current plane (first / last lane)
+  float4 halo;      // one row outside the workgroup tile, current plane (loader waves)
+};
+
+template <int RY, int NW, bool NT, bool FULL>
+__global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs a, int xchunk,
+                                                                     int nzt, int nyt) {
+  constexpr int TY = RY * NW;
+  __shared__ float4 plane[2][TY + 4][64];
+
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int zt = t % nzt;
   const int yt = (t / nzt) % nyt;
   const int xc = t / (nzt * nyt);
 
-  const int y0 = a.y_m + (yt * MARCH_WAVES + wave) * RY;  // first owned row
-  if (y0 > a.y_M) return;                                  // wave-uniform, no barriers below
-  const int zfirst = a.z_m + zt * 256 + lane * 4;          // first owned cell of this lane
-  const bool store_z = zfirst <= a.z_M;
-  // Lanes behind the last owned float4 load the float4 that follows it (it supplies
-  // z+1,z+2 to the last owned lane); further lanes repeat that address.
-  const int zload = min(zfirst, a.z_M + 1);
+  const int yb = a.y_m + yt * TY;  // first row of the workgroup tile
+  const int y0 = yb + wave * RY;   // first owned row of this wave
+  const int zfirst = a.z_m + zt * 256 + lane * 4;
+  const bool store_z = FULL ? true : (zfirst <= a.z_M);
+  const int zload = FULL ? zfirst : min(zfirst, a.z_M + 1);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
 
   const Coef k = load_coef(a);
-  const float *__restrict__ u0 = a.u0;
-  const float *__restrict__ u1 = a.u1;
-  const float *__restrict__ mm = a.m;
-  const long sx = a.sx, sy = a.sy;
+  const unsigned sy = (unsigned)a.sy;
+  const long sxb = a.sx * 4;  // bytes per plane
 
-  // Row offsets (elements, relative to a plane base) of rows y0-2 .. y0+RY+1; rows
-  // past y_M+2 repeat the last readable row so that no load leaves the array.
-  long rowoff[RY + 4];
+  // 32-bit lane byte offsets inside a plane; rows past y_M+2 repeat a readable row
+  unsigned voff[RY], veoff[RY];
+  const bool right_edge = (lane == 63) && store_z;
 #pragma unroll
-  for (int r = 0; r < RY + 4; ++r) {
-    const int y = min(y0 - 2 + r, a.y_M + 2);
-    rowoff[r] = (long)(y + FDTD_HALO) * sy + (zload + FDTD_HALO);
+  for (int r = 0; r < RY; ++r) {
+    const int y = FULL ? (y0 + r) : min(y0 + r, a.y_M + 2);
+    voff[r] = ((unsigned)(y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO)) * 4u;
+    veoff[r] = right_edge ? voff[r] + 16u : voff[r] - 8u;  // (z+4,z+5) for the last lane, else (z-2,z-1)
   }
-  // Edge loads: lane 0 fetches (z-2,z-1) of its float4, lane 63 fetches (z+4,z+5).
-  const bool edge_lane = (lane == 0) || (lane == 63 && store_z);
-  const long edge_shift = (lane == 0) ? -2 : 4;
+  // the two waves at each end of the stack also fetch one row outside the tile
+  const bool halo_loader = (wave < 2) || (wave >= NW - 2);
+  const int halo_y = (wave < 2) ? yb - 2 + wave
+                                : (FULL ? yb + TY + (wave - (NW - 2))
+                                        : min(yb + TY + (wave - (NW - 2)), a.y_M + 2));
+  const int halo_slot = (wave < 2) ? wave : TY + 2 + (wave - (NW - 2));
+  const unsigned vhoff = ((unsigned)(halo_y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO)) * 4u;
 
-  // Register column: col[p][r] holds plane (x-2+p) of owned row r.
-  float4 col[5][RY];
-  float4 halo[4];       // centre plane of rows y0-2, y0-1, y0+RY, y0+RY+1
-  float2 edge[RY];      // centre plane z-edges of the owned rows (edge lanes only)
-  float4 prev[RY], med[RY];  // u1 and m of the centre plane
+  // wave-uniform plane pointers of the first plane
+  const char *pu0 = reinterpret_cast<const char *>(a.u0) + (long)(x_begin + FDTD_HALO) * sxb;
+  const char *pu1 = reinterpret_cast<const char *>(a.u1) + (long)(x_begin + FDTD_HALO) * sxb;
+  const char *pm = reinterpret_cast<const char *>(a.m) + (long)(x_begin + FDTD_HALO) * sxb;
+  char *pu2 = reinterpret_cast<char *>(a.u2) + (long)(x_begin + FDTD_HALO) * sxb;
 
-  {
-    const long base = (long)(x_begin + FDTD_HALO) * sx;
+#define LD4(p, off) (*reinterpret_cast<const float4 *>((p) + (off)))
+#define LD4S(p, off) ld_stream<NT>(reinterpret_cast<const float *>((p) + (off)))
+#define LD2(p, off) (*reinterpret_cast<const float2 *>((p) + (off)))
+
+  float4 col[4][RY];  // planes x-2, x-1, x, x+1 of the owned rows
+  MarchSet<RY> sa, sb;
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) col[p][r] = LD4(pu0 + (p - 2) * sxb, voff[r]);
+    sa.col[r] = LD4(pu0 + 2 * sxb, voff[r]);
+    sa.prev[r] = LD4S(pu1, voff[r]);
+    sa.med[r] = LD4S(pm, voff[r]);
+    sa.edge[r] = LD2(pu0, veoff[r]);
+  }
+  sa.halo = make_float4(0.f, 0.f, 0.f, 0.f);
+  sb.halo = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (halo_loader) sa.halo = LD4(pu0, vhoff);
+
+  // One plane.  `cur` was loaded during the previous iteration; `nxt` is filled now.
+  auto iteration = [&](int x, int buf, const MarchSet<RY> &cur, MarchSet<RY> &nxt)
+                       __attribute__((always_inline)) {
+    // ---- loads for plane x+1 (repeated on plane x at the end of the chunk) ----
+    const long adv = (x < x_end) ? sxb : 0;
+    const char *q0 = pu0 + adv, *q1 = pu1 + adv, *qm = pm + adv;
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-#pragma unroll
-      for (int p = 0; p < 5; ++p)
-        col[p][r] = *reinterpret_cast<const float4 *>(u0 + base + (p - 2) * sx + rowoff[r + 2]);
-      prev[r] = *reinterpret_cast<const float4 *>(u1 + base + rowoff[r + 2]);
-      med[r] = *reinterpret_cast<const float4 *>(mm + base + rowoff[r + 2]);
-      edge[r] = make_float2(0.f, 0.f);
-      if (edge_lane)
-        edge[r] = *reinterpret_cast<const float2 *>(u0 + base + rowoff[r + 2] + edge_shift);
+      nxt.col[r] = LD4(q0 + 2 * sxb, voff[r]);
+      nxt.prev[r] = LD4S(q1, voff[r]);
+      nxt.med[r] = LD4S(qm, voff[r]);
+      nxt.edge[r] = LD2(q0, veoff[r]);
     }
-    halo[0] = *reinterpret_cast<const float4 *>(u0 + base + rowoff[0]);
-    halo[1] = *reinterpret_cast<const float4 *>(u0 + base + rowoff[1]);
-    halo[2] = *reinterpret_cast<const float4 *>(u0 + base + rowoff[RY + 2]);
-    halo[3] = *reinterpret_cast<const float4 *>(u0 + base + rowoff[RY + 3]);
-  }
+    if (halo_loader) nxt.halo = LD4(q0, vhoff);  // wave-uniform branch
 
-  for (int x = x_begin; x <= x_end; ++x) {
-    const long base = (long)(x + FDTD_HALO) * sx;
-    // ---- issue the loads of the next iteration (plane x+1 becomes the centre) ----
-    // At the last plane they are repeated on plane x (in bounds, unused).
-    const long nbase = (x < x_end) ? base + sx : base;
-    float4 ncol[RY], nprev[RY], nmed[RY], nhalo[4];
-    float2 nedge[RY];
+    // ---- publish the centre plane of the owned rows (and the outside row) ----
 #pragma unroll
-    for (int r = 0; r < RY; ++r) {
-      ncol[r] = *reinterpret_cast<const float4 *>(u0 + nbase + 2 * sx + rowoff[r + 2]);
-      nprev[r] = *reinterpret_cast<const float4 *>(u1 + nbase + rowoff[r + 2]);
-      nmed[r] = *reinterpret_cast<const float4 *>(mm + nbase + rowoff[r + 2]);
-      nedge[r] = make_float2(0.f, 0.f);
-      if (edge_lane)
-        nedge[r] = *reinterpret_cast<const float2 *>(u0 + nbase + rowoff[r + 2] + edge_shift);
-    }
-    nhalo[0] = *reinterpret_cast<const float4 *>(u0 + nbase + rowoff[0]);
-    nhalo[1] = *reinterpret_cast<const float4 *>(u0 + nbase + rowoff[1]);
-    nhalo[2] = *reinterpret_cast<const float4 *>(u0 + nbase + rowoff[RY + 2]);
-    nhalo[3] = *reinterpret_cast<const float4 *>(u0 + nbase + rowoff[RY + 3]);
-
-    // ---- compute plane x ----
-    // centre plane of rows y0-2 .. y0+RY+1 (register aliases, no data movement)
+    for (int r = 0; r < RY; ++r) plane[buf][wave * RY + r + 2][lane] = col[2][r];
+    if (halo_loader) plane[buf][halo_slot][lane] = cur.halo;
+    __syncthreads();
     float4 cen[RY + 4];
-    cen[0] = halo[0];
-    cen[1] = halo[1];
+    cen[0] = plane[buf][wave * RY + 0][lane];
+    cen[1] = plane[buf][wave * RY + 1][lane];
 #pragma unroll
     for (int r = 0; r < RY; ++r) cen[r + 2] = col[2][r];
-    cen[RY + 2] = halo[2];
-    cen[RY + 3] = halo[3];
+    cen[RY + 2] = plane[buf][wave * RY + RY + 2][lane];
+    cen[RY + 3] = plane[buf][wave * RY + RY + 3][lane];
+
+    // ---- compute and store plane x ----
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       const float4 c = cen[r + 2];
       const float4 ym2 = cen[r], ym1 = cen[r + 1], yp1 = cen[r + 3], yp2 = cen[r + 4];
-      // z neighbours across lanes
-      const float lz = dpp_from_prev_lane(edge[r].x, c.z);  // z-2 of .x
-      const float lw = dpp_from_prev_lane(edge[r].y, c.w);  // z-1 of .x
-      const float rx = dpp_from_next_lane(edge[r].x, c.x);  // z+1 of .w
-      const float ry = dpp_from_next_lane(edge[r].y, c.y);  // z+2 of .w
-      const float4 xm2 = col[0][r], xm1 = col[1][r], xp1 = col[3][r], xp2 = col[4][r];
-      const float4 up = prev[r], mc = med[r];
+      const float lz = dpp_from_prev_lane(cur.edge[r].x, c.z);
+      const float lw = dpp_from_prev_lane(cur.edge[r].y, c.w);
+      const float rx = dpp_from_next_lane(cur.edge[r].x, c.x);
+      const float ry = dpp_from_next_lane(cur.edge[r].y, c.y);
+      const float4 xm2 = col[0][r], xm1 = col[1][r], xp1 = col[3][r], xp2 = cur.col[r];
+      const float4 up = cur.prev[r], mc = cur.med[r];
       float4 o;
       o.x = update_cell(k, c.x, xm2.x, xm1.x, xp1.x, xp2.x, ym2.x, ym1.x, yp1.x, yp2.x, lz, lw,
                         c.y, c.z, up.x, mc.x);
@@ -253,25 +299,143 @@ __global__ __launch_bounds__(MARCH_WAVES * 64) void stencil_march_kernel(Stencil
                         c.w, rx, up.z, mc.z);
       o.w = update_cell(k, c.w, xm2.w, xm1.w, xp1.w, xp2.w, ym2.w, ym1.w, yp1.w, yp2.w, c.y, c.z,
                         rx, ry, up.w, mc.w);
-      if (store_z && y0 + r <= a.y_M)
-        *reinterpret_cast<float4 *>(a.u2 + base + rowoff[r + 2]) = o;
+      if (FULL || (store_z && y0 + r <= a.y_M))
+        st_stream<NT>(reinterpret_cast<float *>(pu2 + voff[r]), o);
     }
 
-    // ---- rotate the pipeline ----
+    // ---- advance: shift the four older planes, step the plane pointers ----
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
       col[0][r] = col[1][r];
       col[1][r] = col[2][r];
       col[2][r] = col[3][r];
-      col[3][r] = col[4][r];
-      col[4][r] = ncol[r];
-      prev[r] = nprev[r];
-      med[r] = nmed[r];
-      edge[r] = nedge[r];
+      col[3][r] = cur.col[r];
     }
-#pragma unroll
-    for (int h = 0; h < 4; ++h) halo[h] = nhalo[h];
+    pu0 += sxb; pu1 += sxb; pm += sxb; pu2 += sxb;
+  };
+
+  for (int x = x_begin; x <= x_end; x += 2) {
+    iteration(x, 0, sa, sb);
+    if (x + 1 > x_end) break;
+    iteration(x + 1, 1, sb, sa);
   }
+#undef LD4
+#undef LD4S
+#undef LD2
+}
+
+// ---------------------------------------------------------------------------------
+// VEC: one-shot vector kernel.  One lane = one float4 (4 cells in z) of one (x, y) row,
+// one wave = 256 contiguous cells, one workgroup = 4 adjacent rows; nothing loops.  All
+// 9 float4 of u0 a lane needs in x and y (centre, x-2..x+2, y-2..y+2) are plain aligned
+// 16-byte loads; the z-neighbours come from the adjacent lanes by DPP exactly as in the
+// marching kernel.  Reuse is left to the caches, and the launch order is arranged so
+// that they can deliver it:
+//   * the 4 rows of a workgroup are each other's y-neighbours (same CU, same moment);
+//   * workgroup b runs on XCD b % 8; each XCD is given a fixed contiguous range of
+//     y-blocks and walks the planes x = x_m .. x_M in dispatch order, so the five u0
+//     planes a plane needs were brought into that XCD's L2 by the planes just before
+//     (about 1/8 of 5 planes = 0.7 MB at 512^3 against 4 MB of L2).
+// The grid is ~130k short-lived workgroups at 512^3: latency is hidden by residency
+// (8 waves per SIMD), not by a software pipeline.
+// ---------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(256) void stencil_vec_kernel(StencilArgs a, int nzt, int yb_per_xcd,
+                                                          int nyb) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x;
+  const int xcd = b & 7, j = b >> 3;
+  const int per_plane = yb_per_xcd * nzt;
+  const int xi = j / per_plane;
+  const int rem = j - xi * per_plane;
+  const int yb = xcd * yb_per_xcd + rem / nzt;
+  const int zt = rem % nzt;
+  if (yb >= nyb) return;
+  const int y = a.y_m + yb * 4 + wave;
+  if (y > a.y_M) return;
+  const int x = a.x_m + xi;
+  const int zfirst = a.z_m + zt * 256 + lane * 4;
+  const bool store_z = zfirst <= a.z_M;
+  const int zload = min(zfirst, a.z_M + 1);
+
+  const Coef k = load_coef(a);
+  const long sx = a.sx, sy = a.sy;
+  // wave-uniform row base (scalar registers) + per-lane element offset
+  const long row = (long)(x + FDTD_HALO) * sx + (long)(y + FDTD_HALO) * sy + FDTD_HALO;
+  const float *__restrict__ p0 = a.u0 + row;
+  const unsigned voff = (unsigned)zload * 4u;  // zero-extended lane offset: scalar base + vector offset
+#define ROW4(base) (*reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + voff))
+  float4 c = ROW4(p0);
+  const float4 xm2 = ROW4(p0 - 2 * sx);
+  const float4 xm1 = ROW4(p0 - sx);
+  const float4 xp1 = ROW4(p0 + sx);
+  const float4 xp2 = ROW4(p0 + 2 * sx);
+  const float4 ym2 = ROW4(p0 - 2 * sy);
+  const float4 ym1 = ROW4(p0 - sy);
+  const float4 yp1 = ROW4(p0 + sy);
+  const float4 yp2 = ROW4(p0 + 2 * sy);
+#undef ROW4
+  const float4 up = ld_stream<NT>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.u1 + row) + voff));
+  const float4 mc = ld_stream<NT>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.m + row) + voff));
+  float2 edge = make_float2(0.f, 0.f);
+  if (lane == 0 || (lane == 63 && store_z))
+    edge = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(p0 + (lane == 0 ? -2 : 4)) + voff);
+  // keep the centre float4 as loaded (one 16-byte load), opaque to load splitting
+  asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+
+  const float lz = dpp_from_prev_lane(edge.x, c.z);
+  const float lw = dpp_from_prev_lane(edge.y, c.w);
+  const float rx = dpp_from_next_lane(edge.x, c.x);
+  const float ry = dpp_from_next_lane(edge.y, c.y);
+  float4 o;
+  o.x = update_cell(k, c.x, xm2.x, xm1.x, xp1.x, xp2.x, ym2.x, ym1.x, yp1.x, yp2.x, lz, lw, c.y,
+                    c.z, up.x, mc.x);
+  o.y = update_cell(k, c.y, xm2.y, xm1.y, xp1.y, xp2.y, ym2.y, ym1.y, yp1.y, yp2.y, lw, c.x, c.z,
+                    c.w, up.y, mc.y);
+  o.z = update_cell(k, c.z, xm2.z, xm1.z, xp1.z, xp2.z, ym2.z, ym1.z, yp1.z, yp2.z, c.x, c.y, c.w,
+                    rx, up.z, mc.z);
+  o.w = update_cell(k, c.w, xm2.w, xm1.w, xp1.w, xp2.w, ym2.w, ym1.w, yp1.w, yp2.w, c.y, c.z, rx,
+                    ry, up.w, mc.w);
+  if (store_z) st_stream<NT>(reinterpret_cast<float *>(reinterpret_cast<char *>(a.u2 + row) + voff), o);
+}
+
+// ---------------------------------------------------------------------------------
+// TILE3D: the classic cubic LDS tile — an 8x8x8 workgroup (512 threads, one output cell
+// each) stages the 12x12x12 box around its outputs (radius-2 halo on every face) in
+// LDS and reads all 13 stencil points from there; u1 and m come straight from global
+// memory.  One-shot, any shape.  Kept as a selectable variant and as a measurement
+// point: an 8-cell z-extent means 32-byte global segments, so it moves many more cache
+// lines per output than the marching kernel.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void stencil_tile3d_kernel(StencilArgs a, int ntz, int nty) {
+  __shared__ float tile[12][12][13];  // z padded to 13 words: conflict-free y/x column reads
+  const int tid = threadIdx.x;
+  const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int x0 = a.x_m + (t / (ntz * nty)) * 8;
+  const int y0 = a.y_m + ((t / ntz) % nty) * 8;
+  const int z0 = a.z_m + (t % ntz) * 8;
+  const float *__restrict__ u0 = a.u0;
+  for (int i = tid; i < 12 * 12 * 12; i += 512) {
+    const int lz = i % 12, ly = (i / 12) % 12, lx = i / 144;
+    // padded coordinates, clamped into the array for partial tiles at the far faces
+    const int X = min(x0 - 2 + lx + FDTD_HALO, a.nxp - 1);
+    const int Y = min(y0 - 2 + ly + FDTD_HALO, a.nyp - 1);
+    const int Z = min(z0 - 2 + lz + FDTD_HALO, a.nzp - 1);
+    tile[lx][ly][lz] = u0[(long)X * a.sx + (long)Y * a.sy + Z];
+  }
+  __syncthreads();
+  const int lz = tid & 7, ly = (tid >> 3) & 7, lx = tid >> 6;
+  const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+  if (x > a.x_M || y > a.y_M || z > a.z_M) return;
+  const Coef k = load_coef(a);
+  const long c = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
+  const int cx = lx + 2, cy = ly + 2, cz = lz + 2;
+  a.u2[c] = update_cell(k, tile[cx][cy][cz], tile[cx - 2][cy][cz], tile[cx - 1][cy][cz],
+                        tile[cx + 1][cy][cz], tile[cx + 2][cy][cz], tile[cx][cy - 2][cz],
+                        tile[cx][cy - 1][cz], tile[cx][cy + 1][cz], tile[cx][cy + 2][cz],
+                        tile[cx][cy][cz - 2], tile[cx][cy][cz - 1], tile[cx][cy][cz + 1],
+                        tile[cx][cy][cz + 2], a.u1[c], a.m[c]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -348,26 +512,36 @@ static StencilArgs make_args(const fdtd_geom *g, const float *m, float *u, int t
   return a;
 }
 
-template <int RY>
-static void launch_march(const StencilArgs &a, hipStream_t s) {
-  const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
-  const int nzt = (ez + 255) / 256;
-  const int nyt = (ey + MARCH_WAVES * RY - 1) / (MARCH_WAVES * RY);
-  // Choose the x-chunk so that the grid has at least ~4 workgroups per CU, but never
-  // below 8 planes (each chunk re-reads 4 planes of u0 to prime its register column).
+static int pick_xchunk(int ex, long tiles_per_chunk) {
+  // One workgroup per CU marching in step is the sweet spot (neighbouring tiles then
+  // find each other's rows in L2), so aim for ~256 workgroups; never go below 8 planes
+  // per chunk (each chunk re-reads 4 planes of u0 to prime its register column).
   int xchunk = env_int("FDTD_XCHUNK", 0);
   if (xchunk <= 0) {
-    const long want_blocks = 1024;
-    long chunks = (want_blocks + (long)nzt * nyt - 1) / ((long)nzt * nyt);
+    long chunks = (256 + tiles_per_chunk / 2) / tiles_per_chunk;
     if (chunks < 1) chunks = 1;
     xchunk = (int)((ex + chunks - 1) / chunks);
     if (xchunk < 8) xchunk = 8;
-    if (xchunk > ex) xchunk = ex;
   }
+  if (xchunk > ex) xchunk = ex;
+  return xchunk;
+}
+
+template <int RY, int NW, bool NT>
+static void launch_march_lds(const StencilArgs &a, hipStream_t s) {
+  const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
+  const int nzt = (ez + 255) / 256;
+  const int nyt = (ey + NW * RY - 1) / (NW * RY);
+  const int xchunk = pick_xchunk(ex, (long)nzt * nyt);
   const int nxc = (ex + xchunk - 1) / xchunk;
   const long nblocks = (long)nzt * nyt * nxc;
-  hipLaunchKernelGGL(stencil_march_kernel<RY>, dim3((unsigned)nblocks), dim3(MARCH_WAVES * 64), 0, s,
-                     a, xchunk, nzt, nyt);
+  const bool full = (ez % 256 == 0) && (ey % (NW * RY) == 0);
+  if (full)
+    hipLaunchKernelGGL((stencil_march_lds_kernel<RY, NW, NT, true>), dim3((unsigned)nblocks), dim3(NW * 64),
+                       0, s, a, xchunk, nzt, nyt);
+  else
+    hipLaunchKernelGGL((stencil_march_lds_kernel<RY, NW, NT, false>), dim3((unsigned)nblocks), dim3(NW * 64),
+                       0, s, a, xchunk, nzt, nyt);
 }
 
 extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, float *u, int t0,
@@ -381,7 +555,8 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
 
   if (variant == FDTD_VARIANT_AUTO)
     variant = march_eligible(g, m, u) ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
-  if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_TILE3D) && !march_eligible(g, m, u))
+  if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) &&
+      !march_eligible(g, m, u))
     variant = FDTD_VARIANT_NAIVE;
 
   switch (variant) {
@@ -398,12 +573,35 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
       hipLaunchKernelGGL(stencil_naive_kernel, grid, dim3(64, 4, 1), 0, s, a);
       break;
     }
-    case FDTD_VARIANT_MARCH:
+    case FDTD_VARIANT_VEC: {
+      const int nzt = (ez + 255) / 256;
+      const int nyb = (ey + 3) / 4;
+      const int yb_per_xcd = (nyb + 7) / 8;
+      const long nblocks = 8L * yb_per_xcd * nzt * ex;
+      if (nblocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+      if (env_int("FDTD_NT", 1))
+        hipLaunchKernelGGL((stencil_vec_kernel<true>), dim3((unsigned)nblocks), dim3(256), 0, s, a, nzt,
+                           yb_per_xcd, nyb);
+      else
+        hipLaunchKernelGGL((stencil_vec_kernel<false>), dim3((unsigned)nblocks), dim3(256), 0, s, a, nzt,
+                           yb_per_xcd, nyb);
+      break;
+    }
     case FDTD_VARIANT_TILE3D: {
-      const int ry = env_int("FDTD_MARCH_RY", 4);
-      if (ry == 2) launch_march<2>(a, s);
-      else if (ry == 1) launch_march<1>(a, s);
-      else launch_march<4>(a, s);
+      const int ntx = (ex + 7) / 8, nty = (ey + 7) / 8, ntz = (ez + 7) / 8;
+      const long nblocks = (long)ntx * nty * ntz;
+      if (nblocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+      hipLaunchKernelGGL(stencil_tile3d_kernel, dim3((unsigned)nblocks), dim3(512), 0, s, a, ntz, nty);
+      break;
+    }
+    case FDTD_VARIANT_MARCH: {
+      // rows per wave x waves per workgroup; 2 x 8 measured fastest at 512^3
+      const int ry = env_int("FDTD_MARCH_RY", 2), nw = env_int("FDTD_MARCH_NW", 8);
+      const bool nt = env_int("FDTD_NT", 1) != 0;  // non-temporal hints on u1, m, u2
+      if (ry == 2 && nw == 8) nt ? launch_march_lds<2, 8, true>(a, s) : launch_march_lds<2, 8, false>(a, s);
+      else if (ry == 4 && nw == 4) nt ? launch_march_lds<4, 4, true>(a, s) : launch_march_lds<4, 4, false>(a, s);
+      else if (ry == 2 && nw == 4) nt ? launch_march_lds<2, 4, true>(a, s) : launch_march_lds<2, 4, false>(a, s);
+      else return (int)hipErrorInvalidValue;
       break;
     }
     default:

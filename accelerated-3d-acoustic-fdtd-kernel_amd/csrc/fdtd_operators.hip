@@ -222,6 +222,7 @@ static int optimized_variant() {
   if (!strcmp(v, "naive")) return FDTD_VARIANT_NAIVE;
   if (!strcmp(v, "march")) return FDTD_VARIANT_MARCH;
   if (!strcmp(v, "tile3d")) return FDTD_VARIANT_TILE3D;
+  if (!strcmp(v, "vec")) return FDTD_VARIANT_VEC;
   return FDTD_VARIANT_AUTO;
 }
 

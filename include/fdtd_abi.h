@@ -113,6 +113,7 @@ enum fdtd_variant {
   FDTD_VARIANT_NAIVE = 1,    /* 3-D grid, z on lanes, global loads only (cuda.cu)   */
   FDTD_VARIANT_MARCH = 2,    /* x-marching, register column + LDS centre plane      */
   FDTD_VARIANT_TILE3D = 3,   /* 8x8x8 outputs from a 12x12x12 LDS tile              */
+  FDTD_VARIANT_VEC = 4,      /* one-shot float4 lanes, cache-ordered launch          */
   FDTD_VARIANT_AUTO = -1     /* MARCH when the shape allows it, else NAIVE          */
 };
 

@@ -29,6 +29,8 @@ CASES = {
                                       edge_source=True)),
     "odd_sizes": ("random", dict(n=(17, 33, 65), nt=9, nsrc=3, h=(1.0, 1.0, 1.0), seed=12)),
     "tile_edges_100": ("random", dict(n=(12, 100, 260), nt=7, nsrc=1, h=(1.0, 0.9, 1.1), seed=13)),
+    # every tile of the marching kernel is full here (z extent 256, y extent 32): its branch-free path
+    "full_tiles_256": ("random", dict(n=(11, 32, 256), nt=7, nsrc=1, h=(1.0, 1.1, 0.9), seed=18)),
     "subrange_aligned": ("random", dict(n=(32, 32, 32), nt=10, nsrc=2, h=(1.0, 1.0, 1.0), seed=14,
                                         bounds=(3, 20, 2, 29, 4, 27))),
     "subrange_unaligned": ("random", dict(n=(32, 32, 32), nt=10, nsrc=2, h=(1.0, 1.0, 1.0), seed=15,
