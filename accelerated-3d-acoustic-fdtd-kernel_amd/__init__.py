@@ -6,6 +6,7 @@ binds that library with ctypes and adds the multi-GPU slab propagator; there is 
 CPU fallback — importing :mod:`abi` raises if the library is missing.
 """
 from . import abi  # noqa: F401
+from . import slab  # noqa: F401
 from .abi import (  # noqa: F401
     HALO,
     WARMUP_STEPS,

@@ -91,6 +91,9 @@ def lib():
                                          C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p]
     L.fdtd_hip_source_inject.restype = C.c_int
+    L.fdtd_hip_source_inject_slab.argtypes = L.fdtd_hip_source_inject.argtypes[:-1] + [
+        C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_source_inject_slab.restype = C.c_int
     L.fdtd_hip_time_loop.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.POINTER(Profiler)]

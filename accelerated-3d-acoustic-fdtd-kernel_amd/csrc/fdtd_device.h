@@ -31,6 +31,10 @@ struct InjectArgs {
   int p_src_m, p_src_M;
   int time;
   int src_stride, coord_stride;
+  // Slab decomposition along x: the arrays hold global planes x_shift-4 .. ; a corner
+  // is applied iff its GLOBAL x index lies in [x_lo, x_hi].  Single-domain calls use
+  // x_shift = 0, x_lo = x_m - 1, x_hi = x_M + 1 (openacc.cpp:192).
+  int x_shift, x_lo, x_hi;
 };
 
 #define FDTD_HIP_CHECK(expr)                  \

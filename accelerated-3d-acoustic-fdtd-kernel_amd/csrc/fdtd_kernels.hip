@@ -457,13 +457,13 @@ __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
   const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
   const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
 
-  if (rx + posx >= a.x_m - 1 && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
-      rx + posx <= a.x_M + 1 && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
+  if (rx + posx >= a.x_lo && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
+      rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
     const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
                      (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
-                     a.m[(long)(posx + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
+                     a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
                          (posz + FDTD_HALO)];
-    atomicAdd(a.u2 + (long)(rx + posx + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
+    atomicAdd(a.u2 + (long)(rx + posx - a.x_shift + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
                   (rz + posz + FDTD_HALO),
               r0);
   }
@@ -610,14 +610,14 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
   return (int)hipGetLastError();
 }
 
-extern "C" int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m, const float *src,
-                                      const float *src_coords, float *u, int t2, int time,
-                                      int p_src_m, int p_src_M, int src_stride, int coord_stride,
-                                      void *stream) {
+static int launch_inject(const struct fdtd_geom *g, const float *m, const float *src,
+                         const float *src_coords, float *u, int t2, int time, int p_src_m, int p_src_M,
+                         int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, void *stream) {
   if (p_src_M < p_src_m) return 0;
   if (!g || !m || !src || !src_coords || !u || t2 < 0 || t2 > 2 || coord_stride < 3 ||
       src_stride < 1)
     return (int)hipErrorInvalidValue;
+  if (x_hi < x_lo) return 0;
   InjectArgs a;
   const long vol = (long)g->nxp * g->nyp * g->nzp;
   a.m = m; a.src = src; a.coords = src_coords;
@@ -627,10 +627,28 @@ extern "C" int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m,
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
   a.p_src_m = p_src_m; a.p_src_M = p_src_M; a.time = time;
   a.src_stride = src_stride; a.coord_stride = coord_stride;
+  a.x_shift = x_shift; a.x_lo = x_lo; a.x_hi = x_hi;
   const long threads = (long)(p_src_M - p_src_m + 1) * 8;
   hipLaunchKernelGGL(source_inject_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+extern "C" int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m, const float *src,
+                                      const float *src_coords, float *u, int t2, int time,
+                                      int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                                      void *stream) {
+  if (!g) return (int)hipErrorInvalidValue;
+  return launch_inject(g, m, src, src_coords, u, t2, time, p_src_m, p_src_M, src_stride, coord_stride,
+                       0, g->x_m - 1, g->x_M + 1, stream);
+}
+
+extern "C" int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m, const float *src,
+                                           const float *src_coords, float *u, int t2, int time,
+                                           int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                                           int x_shift, int x_lo, int x_hi, void *stream) {
+  return launch_inject(g, m, src, src_coords, u, t2, time, p_src_m, p_src_M, src_stride, coord_stride,
+                       x_shift, x_lo, x_hi, stream);
 }
 
 // ---------------------------------------------------------------------------------
@@ -687,13 +705,13 @@ __global__ __launch_bounds__(256) void source_inject_h16_kernel(InjectArgsH16 h)
   const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
   const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
   const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
-  if (rx + posx >= a.x_m - 1 && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
-      rx + posx <= a.x_M + 1 && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
+  if (rx + posx >= a.x_lo && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
+      rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
     const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
                      (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
-                     a.m[(long)(posx + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
+                     a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
                          (posz + FDTD_HALO)];
-    const long c = (long)(rx + posx + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
+    const long c = (long)(rx + posx - a.x_shift + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
                    (rz + posz + FDTD_HALO);
     unsigned int *word = reinterpret_cast<unsigned int *>(h.u2) + (c >> 1);
     const int shift = (c & 1) ? 16 : 0;
@@ -756,6 +774,7 @@ extern "C" int fdtd_hip_source_inject_h16(const struct fdtd_geom *g, const float
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
   a.p_src_m = p_src_m; a.p_src_M = p_src_M; a.time = time;
   a.src_stride = src_stride; a.coord_stride = coord_stride;
+  a.x_shift = 0; a.x_lo = g->x_m - 1; a.x_hi = g->x_M + 1;
   const long threads = (long)(p_src_M - p_src_m + 1) * 8;
   hipLaunchKernelGGL(source_inject_h16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, h);

@@ -1,0 +1,315 @@
+"""Multi-GPU propagation: the grid is cut into slabs along x, the slowest storage axis, one slab
+per process/GPU (torch.distributed; backend "nccl" is RCCL over xGMI).
+
+The reference is single-device (no counterpart); the arithmetic per cell is unchanged
+(openacc.cpp:159-164, 185-196), so the union of the slabs is bit-identical to a single-domain
+run.  What is new is the data movement:
+
+* storage: rank r owns global planes [x_off, x_off + nx_loc) and keeps them in a local array
+  with the usual 4-plane padding on both sides.  The inner two padding planes are the ghosts
+  (copies of the neighbour's outermost owned planes); on the first/last rank they are the
+  physical halo.  Every ghost block is one contiguous span of 2*nyp*nzp floats, so no pack or
+  unpack kernels exist.  (Cutting along the contiguous z axis instead would turn each ghost
+  "plane" into a stride-nzp gather of 2-float pieces.)
+* per step: (1) update the two outermost owned planes on each side, (2) scatter the sources
+  that land there, (3) hand exactly those planes of the new level to the neighbours — two
+  point-to-point messages per neighbour, no collective — on a second stream while (4) the
+  interior planes are updated and (5) the remaining sources are scattered.  The next step's
+  boundary update waits for the messages; its interior update does not.
+* a source corner is applied by the rank that owns its global x index (first/last rank also
+  own the physical halo plane next to them, openacc.cpp:192), so each corner is added once.
+
+`stepper` supplies the kernels (HipStepper: libfdtd_hip.so on the GPU; the tests drive the same
+orchestration with a CPU stepper built on the oracle).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+HALO = abi.HALO
+GHOST = 2  # radius of the stencil = planes exchanged per side
+
+
+class SlabLayout:
+    """Index arithmetic of the x-slab decomposition of NX interior planes over `world` ranks."""
+
+    def __init__(self, NX, world):
+        if world < 1 or NX < world:
+            raise ValueError("need at least one plane per rank")
+        base, rem = divmod(NX, world)
+        self.NX, self.world = NX, world
+        self.counts = [base + (1 if r < rem else 0) for r in range(world)]
+        self.offsets = [sum(self.counts[:r]) for r in range(world)]
+        if world > 1 and min(self.counts) < GHOST:
+            raise ValueError("slabs thinner than the stencil radius are not supported")
+
+    def nx_loc(self, rank):
+        return self.counts[rank]
+
+    def x_off(self, rank):
+        return self.offsets[rank]
+
+    def owned_corner_range(self, rank):
+        """Global x indices of scatter targets this rank applies (inclusive)."""
+        lo = self.offsets[rank] if rank > 0 else -1
+        hi = self.offsets[rank] + self.counts[rank] - 1 if rank < self.world - 1 else self.NX
+        return lo, hi
+
+    def cut(self, global_padded, rank, axis):
+        """Local padded view [x_off, x_off + nx_loc + 8) of a globally padded array along `axis`."""
+        sl = [slice(None)] * global_padded.ndim
+        sl[axis] = slice(self.offsets[rank], self.offsets[rank] + self.counts[rank] + 2 * HALO)
+        return global_padded[tuple(sl)]
+
+    def paste_owned(self, global_padded, local_padded, rank, axis):
+        """Write a rank's owned planes (plus the physical halo on the first/last rank) back."""
+        lo, hi = HALO, HALO + self.counts[rank]
+        if rank == 0:
+            lo = 0
+        if rank == self.world - 1:
+            hi = self.counts[rank] + 2 * HALO
+        src = [slice(None)] * local_padded.ndim
+        dst = [slice(None)] * global_padded.ndim
+        src[axis] = slice(lo, hi)
+        dst[axis] = slice(self.offsets[rank] + lo, self.offsets[rank] + hi)
+        global_padded[tuple(dst)] = local_padded[tuple(src)]
+
+
+def source_floor_planes(coords, o_x, h_x):
+    """floor((-o_x + c_x)/h_x) per source, in binary32 like openacc.cpp:185."""
+    c = np.asarray(coords, dtype=np.float32)[:, 0]
+    g = (np.float32(-o_x) + c) / np.float32(h_x)
+    return np.floor(g).astype(np.int64)
+
+
+class SlabPropagator:
+    """Time stepping of one slab.  `u` is the local [3][nx_loc+8][nyp][nzp] tensor, `m` the local
+    [nx_loc+8][nyp][nzp] tensor (both torch tensors on the stepper's device, ghosts filled)."""
+
+    def __init__(self, layout, rank, u, m, src, coords, *, dt, h, o, stepper, comm):
+        self.layout, self.rank = layout, rank
+        self.u, self.m = u, m
+        self.nx = layout.nx_loc(rank)
+        self.x_off = layout.x_off(rank)
+        self.dt, self.h, self.o = dt, h, o
+        self.stepper, self.comm = stepper, comm
+        self.nsrc = 0 if src is None else int(src.shape[1])
+        self.src, self.coords = src, coords
+        lo, hi = layout.owned_corner_range(rank)
+        # regions of owned scatter targets: left boundary, right boundary, interior (global x)
+        nx, xo = self.nx, self.x_off
+        self.overlap = layout.world > 1 and nx >= 2 * GHOST + 1
+        if self.overlap:
+            self.regions = {
+                "left": (lo, xo + GHOST - 1),
+                "right": (xo + nx - GHOST, hi),
+                "interior": (xo + GHOST, xo + nx - GHOST - 1),
+            }
+        else:
+            self.regions = {"all": (lo, hi)}
+        # which regions can receive a corner at all (decided once, on the host)
+        self.active = {k: False for k in self.regions}
+        if self.nsrc > 0:
+            coords_host = coords.detach().cpu().numpy() if hasattr(coords, "detach") else np.asarray(coords)
+            pos = source_floor_planes(coords_host, o[0], h[0])
+            for k, (a, b) in self.regions.items():
+                self.active[k] = bool(((pos + 1 >= a) & (pos <= b)).any())
+        stepper.bind(self)
+
+    # ---- one time step (ring indices as openacc.cpp:148) ----
+    def step(self, time):
+        t0, t1, t2 = time % 3, (time + 2) % 3, (time + 1) % 3
+        st, nx = self.stepper, self.nx
+        st.begin_step()
+        if self.overlap:
+            st.stencil(0, GHOST - 1, t0, t1, t2, boundary=True)
+            st.stencil(nx - GHOST, nx - 1, t0, t1, t2, boundary=True)
+            for k in ("left", "right"):
+                if self.active[k]:
+                    st.inject(self.regions[k], t2, time)
+            st.boundary_done()
+            self.comm.exchange(self, t2)
+            st.stencil(GHOST, nx - GHOST - 1, t0, t1, t2, boundary=False)
+            if self.active["interior"]:
+                st.inject(self.regions["interior"], t2, time)
+        else:
+            st.stencil(0, nx - 1, t0, t1, t2, boundary=False)
+            if self.active["all"]:
+                st.inject(self.regions["all"], t2, time)
+            st.boundary_done()
+            self.comm.exchange(self, t2)
+
+    def run(self, time_m, time_M):
+        for time in range(time_m, time_M + 1):
+            self.step(time)
+        self.stepper.finish()
+
+    # planes of level `lvl` sent to / received from the neighbours (contiguous tensor views)
+    def send_left(self, lvl):
+        return self.u[lvl, HALO:HALO + GHOST]
+
+    def send_right(self, lvl):
+        return self.u[lvl, HALO + self.nx - GHOST:HALO + self.nx]
+
+    def recv_left(self, lvl):
+        return self.u[lvl, HALO - GHOST:HALO]
+
+    def recv_right(self, lvl):
+        return self.u[lvl, HALO + self.nx:HALO + self.nx + GHOST]
+
+    # ---- benchmark helpers ----
+    def interior_cells(self):
+        nyp, nzp = self.u.shape[2], self.u.shape[3]
+        planes = self.nx - 2 * GHOST if self.overlap else self.nx
+        return float(planes) * (nyp - 2 * HALO) * (nzp - 2 * HALO)
+
+    def mean_interior_kernel_ms(self):
+        return self.stepper.mean_interior_kernel_ms()
+
+    @classmethod
+    def standard_benchmark(cls, n_per_rank, ny, nz, nt, rank, world, device, variant=-1):
+        """Weak-scaling benchmark state: global (n_per_rank*world) x ny x nz grid, u = 0, m = 1.5,
+        h = 0.1, dt = 1e-3, one Ricker source at a quarter of the global extents
+        (main.cpp:285-356 applied to the global grid), built directly on the device."""
+        import torch
+        import torch.distributed as dist
+        layout = SlabLayout(n_per_rank * world, world)
+        nx = layout.nx_loc(rank)
+        shape = (nx + 2 * HALO, ny + 2 * HALO, nz + 2 * HALO)
+        u = torch.zeros((3,) + shape, dtype=torch.float32, device=device)
+        m = torch.full(shape, 1.5, dtype=torch.float32, device=device)
+        src = torch.from_numpy(abi.fill_ricker(nt, 1)).to(device)
+        coords = torch.from_numpy(abi.fill_source_coords(1, n_per_rank * world, ny, nz)).to(device)
+        stepper = HipStepper(device, variant=variant, time_interior=True)
+        comm = TorchComm(dist, rank, world, stepper)
+        return cls(layout, rank, u, m, src, coords, dt=1e-3, h=(0.1, 0.1, 0.1), o=(0.0, 0.0, 0.0),
+                   stepper=stepper, comm=comm)
+
+
+class HipStepper:
+    """Kernels from libfdtd_hip.so on two HIP streams: `compute` for the stencil and the scatter,
+    `comm` for the ghost messages."""
+
+    def __init__(self, device, variant=-1, time_interior=False):
+        import torch
+        self.torch = torch
+        self.lib = abi.lib()
+        self.device = device
+        self.variant = variant
+        self.compute = torch.cuda.current_stream(device)
+        self.comm_stream = torch.cuda.Stream(device)
+        self.ev_boundary = torch.cuda.Event()
+        self.ev_ghosts = torch.cuda.Event()
+        self.have_ghost_event = False
+        self.time_interior = time_interior
+        self.timing = []
+
+    def bind(self, prop):
+        self.p = prop
+        nxp, nyp, nzp = prop.u.shape[1:]
+        self.geom = abi.Geom(nxp, nyp, nzp, 0, prop.nx - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1,
+                             prop.dt, prop.h[0], prop.h[1], prop.h[2], prop.o[0], prop.o[1], prop.o[2])
+        self.u_ptr, self.m_ptr = prop.u.data_ptr(), prop.m.data_ptr()
+        self.src_ptr = prop.src.data_ptr() if prop.nsrc else None
+        self.coords_ptr = prop.coords.data_ptr() if prop.nsrc else None
+        self.sh = C.c_void_p(self.compute.cuda_stream)
+
+    def begin_step(self):
+        # the boundary update reads the ghosts delivered by the previous step's messages
+        if self.have_ghost_event:
+            self.compute.wait_event(self.ev_ghosts)
+
+    def stencil(self, x_lo, x_hi, t0, t1, t2, boundary):
+        if x_hi < x_lo:
+            return
+        g = abi.Geom.from_buffer_copy(self.geom)
+        g.x_m, g.x_M = x_lo, x_hi
+        timed = self.time_interior and not boundary
+        if timed:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.compute)
+        rc = self.lib.fdtd_hip_stencil_step(C.byref(g), self.m_ptr, self.u_ptr, t0, t1, t2, self.variant, self.sh)
+        if rc:
+            raise RuntimeError(f"fdtd_hip_stencil_step failed with hipError {rc}")
+        if timed:
+            e1.record(self.compute)
+            self.timing.append((e0, e1))
+
+    def inject(self, region, t2, time):
+        p = self.p
+        rc = self.lib.fdtd_hip_source_inject_slab(
+            C.byref(self.geom), self.m_ptr, self.src_ptr, self.coords_ptr, self.u_ptr, t2, time,
+            0, p.nsrc - 1, p.src.shape[1], p.coords.shape[1], p.x_off, region[0], region[1], self.sh)
+        if rc:
+            raise RuntimeError(f"fdtd_hip_source_inject_slab failed with hipError {rc}")
+
+    def boundary_done(self):
+        self.ev_boundary.record(self.compute)
+
+    def finish(self):
+        self.compute.wait_event(self.ev_ghosts) if self.have_ghost_event else None
+        self.torch.cuda.synchronize(self.device)
+
+    def mean_interior_kernel_ms(self):
+        self.torch.cuda.synchronize(self.device)
+        if not self.timing:
+            return float("nan")
+        # skip the untimed warm-up launches at the front of the list if there are enough samples
+        ev = self.timing[len(self.timing) // 4:]
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+class TorchComm:
+    """Ghost exchange with torch.distributed point-to-point messages (RCCL on GPUs).
+
+    With the "nccl" backend the messages are enqueued on the stepper's second stream behind the
+    boundary event, so they overlap the interior update.  With "gloo" (CPU tests, or several ranks
+    sharing one GPU) device tensors are staged through the host."""
+
+    def __init__(self, dist, rank, world, stepper=None):
+        self.dist, self.rank, self.world, self.stepper = dist, rank, world, stepper
+        self.backend = dist.get_backend() if world > 1 else None
+
+    def exchange(self, prop, lvl):
+        if self.world == 1:
+            return
+        dist, r = self.dist, self.rank
+        st = self.stepper
+        on_gpu = prop.u.is_cuda
+        if on_gpu and self.backend == "nccl":
+            torch = st.torch
+            with torch.cuda.stream(st.comm_stream):
+                st.comm_stream.wait_event(st.ev_boundary)
+                ops = []
+                if r > 0:
+                    ops.append(dist.P2POp(dist.isend, prop.send_left(lvl), r - 1))
+                    ops.append(dist.P2POp(dist.irecv, prop.recv_left(lvl), r - 1))
+                if r < self.world - 1:
+                    ops.append(dist.P2POp(dist.isend, prop.send_right(lvl), r + 1))
+                    ops.append(dist.P2POp(dist.irecv, prop.recv_right(lvl), r + 1))
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                st.ev_ghosts.record(st.comm_stream)
+                st.have_ghost_event = True
+            return
+        # host-staged path
+        if on_gpu:
+            st.torch.cuda.synchronize(st.device)
+        stage = (lambda t: t.cpu().contiguous()) if on_gpu else (lambda t: t.contiguous())
+        reqs, recvs = [], []
+        if r > 0:
+            reqs.append(dist.isend(stage(prop.send_left(lvl)), r - 1))
+            buf = stage(prop.recv_left(lvl))
+            reqs.append(dist.irecv(buf, r - 1))
+            recvs.append((prop.recv_left(lvl), buf))
+        if r < self.world - 1:
+            reqs.append(dist.isend(stage(prop.send_right(lvl)), r + 1))
+            buf = stage(prop.recv_right(lvl))
+            reqs.append(dist.irecv(buf, r + 1))
+            recvs.append((prop.recv_right(lvl), buf))
+        for q in reqs:
+            q.wait()
+        for dst, buf in recvs:
+            dst.copy_(buf)

@@ -75,8 +75,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 through: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank; the modulo only matters when the N>1 path is rehearsed on a 1-GPU box
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     n = args.grid
     K, W = args.steps, args.warmup
@@ -85,8 +87,13 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-        from __graft_entry__ import load_package as _lp  # noqa: F401
+        # "nccl" is RCCL on ROCm.  FDTD_BENCH_BACKEND=gloo stages the ghosts through the host
+        # (for rehearsing this path with several ranks on one GPU; never a performance number).
+        backend = os.environ.get("FDTD_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         slab = pkg.slab
         prop = slab.SlabPropagator.standard_benchmark(n_per_rank=n, ny=n, nz=n, nt=total_steps,
                                                      rank=rank, world=world, device=dev,

@@ -141,6 +141,19 @@ int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m,
                            int t2, int time, int p_src_m, int p_src_M,
                            int src_stride, int coord_stride, void *stream);
 
+/* Slab form of the scatter, for a grid cut into slabs along x (the slowest axis) with one
+ * slab per GPU.  The arrays hold the slab whose first interior plane is GLOBAL plane
+ * x_shift; coordinates, origin and spacing stay global, so positions and weights are the
+ * very numbers the single-domain call computes.  A corner is applied iff its global x index
+ * lies in [x_lo, x_hi] (the y and z tests are those of openacc.cpp:192).  With x_shift = 0,
+ * x_lo = x_m-1, x_hi = x_M+1 this is fdtd_hip_source_inject.  No counterpart in the reference
+ * (single device only); the arithmetic is openacc.cpp:185-196. */
+int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
+                                const float *src, const float *src_coords, float *u,
+                                int t2, int time, int p_src_m, int p_src_M,
+                                int src_stride, int coord_stride, int x_shift, int x_lo,
+                                int x_hi, void *stream);
+
 /* The whole time loop on device-resident fields: steps time_m..time_M, ring
  * indexing and section timers exactly as the operators do (timers may be NULL, in
  * which case nothing is timed and no host synchronisation happens before return

@@ -83,7 +83,10 @@ static void oracle_section1(const float *restrict m, const float *restrict src,
                             int z_m, int z_M, float h_x, float h_y, float h_z,
                             float o_x, float o_y, float o_z, int p_src_m,
                             int p_src_M, int time, long src_stride,
-                            long coord_stride) {
+                            long coord_stride, int x_shift, int x_lo, int x_hi) {
+  /* x_shift/x_lo/x_hi: slab form used by the decomposition tests (arrays hold global planes
+   * x_shift-4.., a corner is applied iff its global x lies in [x_lo, x_hi]); the reference
+   * itself is the case x_shift = 0, x_lo = x_m-1, x_hi = x_M+1. */
   const long sx = nyp * nzp, sy = nzp;
   for (int p = p_src_m; p <= p_src_M; p += 1) {
     for (int rx = 0; rx <= 1; rx += 1) {
@@ -98,14 +101,16 @@ static void oracle_section1(const float *restrict m, const float *restrict src,
           const float px = -floorf(gx) + gx;
           const float py = -floorf(gy) + gy;
           const float pz = -floorf(gz) + gz;
-          if (rx + posx >= x_m - 1 && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
-              rx + posx <= x_M + 1 && ry + posy <= y_M + 1 && rz + posz <= z_M + 1) {
+          (void)x_m;
+          (void)x_M;
+          if (rx + posx >= x_lo && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
+              rx + posx <= x_hi && ry + posy <= y_M + 1 && rz + posz <= z_M + 1) {
             const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) *
                              (ry * py + (1 - ry) * (1 - py)) *
                              (rz * pz + (1 - rz) * (1 - pz)) *
                              src[(long)time * src_stride + p] /
-                             m[(long)(posx + 4) * sx + (long)(posy + 4) * sy + (posz + 4)];
-            u2[(long)(rx + posx + 4) * sx + (long)(ry + posy + 4) * sy +
+                             m[(long)(posx - x_shift + 4) * sx + (long)(posy + 4) * sy + (posz + 4)];
+            u2[(long)(rx + posx - x_shift + 4) * sx + (long)(ry + posy + 4) * sy +
                (rz + posz + 4)] += r0;
           }
         }
@@ -144,7 +149,7 @@ int Oracle_Kernel_OpenACC(FDTD_OPERATOR_ARGS) {
     if (has_src)
       oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
                       z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time,
-                      src_stride, coord_stride);
+                      src_stride, coord_stride, 0, x_m - 1, x_M + 1);
     if (timed) {
       double c = now_s();
       timers->section0 += b - a;
@@ -178,7 +183,19 @@ void oracle_source_inject(const float *m, const float *src, const float *coords,
   const long vol = nxp * nyp * nzp;
   oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
                   z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time,
-                  src_stride, coord_stride);
+                  src_stride, coord_stride, 0, x_m - 1, x_M + 1);
+}
+
+void oracle_source_inject_slab(const float *m, const float *src, const float *coords,
+                               float *u, long nxp, long nyp, long nzp, int y_m, int y_M,
+                               int z_m, int z_M, float h_x, float h_y, float h_z, float o_x,
+                               float o_y, float o_z, int p_src_m, int p_src_M, int time,
+                               long src_stride, long coord_stride, int t2, int x_shift,
+                               int x_lo, int x_hi) {
+  const long vol = nxp * nyp * nzp;
+  oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, 0, 0, y_m, y_M, z_m, z_M, h_x,
+                  h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time, src_stride, coord_stride,
+                  x_shift, x_lo, x_hi);
 }
 
 /* main.cpp:573-593, the driver's parity metrics, restated independently of the

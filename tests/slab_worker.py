@@ -1,0 +1,98 @@
+"""One rank of a slab-decomposed run (spawned by the slab tests).
+
+usage: python slab_worker.py <stepper: oracle|hip> <case> <outdir>     (RANK/WORLD_SIZE/MASTER_* in env)
+Every rank builds the same global case, cuts its slab (ghosts included), runs the SlabPropagator
+and saves its local wavefield; the parent reassembles and compares with a single-domain run.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import cases  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+HALO = 4
+
+
+class OracleStepper:
+    """CPU stepper for the orchestration tests: the oracle's sweeps on the local numpy arrays."""
+
+    def __init__(self):
+        import oracle_binding as ob
+        self.ob = ob
+
+    def bind(self, prop):
+        self.p = prop
+        self.u = prop.u.numpy()
+        self.m = prop.m.numpy()
+        self.src = prop.src.numpy() if prop.nsrc else None
+        self.coords = prop.coords.numpy() if prop.nsrc else None
+
+    def begin_step(self):
+        pass
+
+    def stencil(self, x_lo, x_hi, t0, t1, t2, boundary):
+        if x_hi < x_lo:
+            return
+        nyp, nzp = self.u.shape[2:]
+        self.ob.oracle_stencil_step(self.m, self.u, (x_lo, x_hi, 0, nyp - 9, 0, nzp - 9),
+                                    np.float32(self.p.dt), tuple(np.float32(v) for v in self.p.h), t0, t1, t2)
+
+    def inject(self, region, t2, time):
+        p = self.p
+        nxp, nyp, nzp = self.u.shape[1:]
+        self.ob.oracle().oracle_source_inject_slab(
+            self.m.ctypes.data, self.src.ctypes.data, self.coords.ctypes.data, self.u.ctypes.data,
+            nxp, nyp, nzp, 0, nyp - 9, 0, nzp - 9, *[float(v) for v in p.h], *[float(v) for v in p.o],
+            0, p.nsrc - 1, time, self.src.shape[1], self.coords.shape[1], t2, p.x_off, region[0], region[1])
+
+    def boundary_done(self):
+        pass
+
+    def finish(self):
+        pass
+
+
+def main():
+    kind, name, outdir = sys.argv[1:4]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_package()
+    c = cases.build(name, pkg)
+    kw = c["kw"]
+    h = kw.get("h", (0.1, 0.1, 0.1))
+    dt = kw.get("dt", 1e-3)
+    NX = c["u"].shape[1] - 2 * HALO
+    layout = pkg.slab.SlabLayout(NX, world)
+    u_loc = np.ascontiguousarray(layout.cut(c["u"], rank, axis=1))
+    m_loc = np.ascontiguousarray(layout.cut(c["m"], rank, axis=0))
+    time_m = kw.get("time_m", 0)
+    time_M = kw.get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
+    if kind == "oracle":
+        dev = "cpu"
+        stepper = OracleStepper()
+    else:
+        dev = torch.device("cuda", 0)
+        stepper = pkg.slab.HipStepper(dev, variant=pkg.VARIANTS["auto"])
+    u_t = torch.from_numpy(u_loc).to(dev)
+    m_t = torch.from_numpy(m_loc).to(dev)
+    src_t = None if c["src"] is None else torch.from_numpy(c["src"]).to(dev)
+    coords_t = None if c["coords"] is None else torch.from_numpy(c["coords"]).to(dev)
+    comm = pkg.slab.TorchComm(dist, rank, world, stepper)
+    prop = pkg.slab.SlabPropagator(layout, rank, u_t, m_t, src_t, coords_t, dt=dt, h=h, o=(0.0, 0.0, 0.0),
+                                   stepper=stepper, comm=comm)
+    prop.run(time_m, time_M)
+    np.save(os.path.join(outdir, f"u_rank{rank}.npy"), u_t.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
