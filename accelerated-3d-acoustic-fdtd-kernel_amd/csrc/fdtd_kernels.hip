@@ -513,17 +513,30 @@ static StencilArgs make_args(const fdtd_geom *g, const float *m, float *u, int t
 }
 
 static int pick_xchunk(int ex, long tiles_per_chunk) {
-  // One workgroup per CU marching in step is the sweet spot (neighbouring tiles then
-  // find each other's rows in L2), so aim for ~256 workgroups; never go below 8 planes
-  // per chunk (each chunk re-reads 4 planes of u0 to prime its register column).
+  // The marching kernel keeps one workgroup per CU resident, so the grid runs in rounds of
+  // 256 workgroups.  Pick the number of x-chunks that wastes the least of the last round;
+  // among equals prefer fewer, longer chunks (each chunk re-reads 4 planes of u0 to prime
+  // its register column, and one round of workgroups marching in step is what lets
+  // neighbouring tiles find each other's rows in L2).  Never below 8 planes per chunk.
   int xchunk = env_int("FDTD_XCHUNK", 0);
   if (xchunk <= 0) {
-    long chunks = (256 + tiles_per_chunk / 2) / tiles_per_chunk;
-    if (chunks < 1) chunks = 1;
-    xchunk = (int)((ex + chunks - 1) / chunks);
-    if (xchunk < 8) xchunk = 8;
+    const long cus = 256;
+    long best_chunks = 1;
+    double best_score = -1.0;
+    const long max_chunks = ex / 8 > 0 ? ex / 8 : 1;
+    for (long chunks = 1; chunks <= max_chunks && chunks <= 64; ++chunks) {
+      const long blocks = chunks * tiles_per_chunk;
+      const long rounds = (blocks + cus - 1) / cus;
+      const double fill = (double)blocks / (double)(rounds * cus);
+      const long planes = (ex + chunks - 1) / chunks;
+      const double prologue = (double)planes / (double)(planes + 4);  // useful share of u0 plane loads
+      const double score = fill * (0.75 + 0.25 * prologue);
+      if (score > best_score + 1e-9) { best_score = score; best_chunks = chunks; }
+    }
+    xchunk = (int)((ex + best_chunks - 1) / best_chunks);
   }
   if (xchunk > ex) xchunk = ex;
+  if (xchunk < 1) xchunk = 1;
   return xchunk;
 }
 
@@ -553,8 +566,13 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
   hipStream_t s = (hipStream_t)stream;
   const StencilArgs a = make_args(g, m, u, t0, t1, t2);
 
-  if (variant == FDTD_VARIANT_AUTO)
-    variant = march_eligible(g, m, u) ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
+  if (variant == FDTD_VARIANT_AUTO) {
+    // Measured crossover on MI355X: below ~160^3 cells a sweep is a handful of microseconds
+    // and the one-cell-per-thread kernel (most workgroups, no prologue) wins; from 192^3 on
+    // the marching kernel does.
+    const long cells = (long)ex * ey * ez;
+    variant = (march_eligible(g, m, u) && cells >= 6000000L) ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
+  }
   if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) &&
       !march_eligible(g, m, u))
     variant = FDTD_VARIANT_NAIVE;

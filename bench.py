@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--grid", type=int, default=512, help="cells per axis (per-rank slab thickness for N>1)")
     ap.add_argument("--variant", default="auto", choices=["auto", "flat", "naive", "march", "tile3d", "vec"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12, help="oracle steps for the CPU baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=50, help="oracle steps for the CPU baseline sample")
     return ap.parse_args()
 
 

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
+#   1. --kernel-trace --stats of `python3 bench.py` (per-kernel average durations)
+#   2. separate --pmc passes for FETCH_SIZE and WRITE_SIZE (HBM-side traffic of the stencil kernel)
+# Results land in gpurun_out/profile_<tag>/ ; copy the summaries into profiles/ afterwards.
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profile_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --steps 10 > $O/fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --steps 10 > $O/write.log 2>&1 || exit 1
+python3 - "$O" <<'PY'
+import csv, glob, collections, json, sys
+O = sys.argv[1]
+out = {}
+for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(f"{O}/{d}/*/*_counter_collection.csv")[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "stencil_march" in r["Kernel_Name"]]
+    out[c + "_KB_per_launch"] = sum(vals) / len(vals)
+    out[c + "_launches"] = len(vals)
+# gfx950: FETCH_SIZE reports half of the bytes of a wide coalesced streaming read; WRITE_SIZE is exact
+out["hbm_read_bytes_per_launch"] = 2 * 1024 * out["FETCH_SIZE_KB_per_launch"]
+out["hbm_write_bytes_per_launch"] = 1024 * out["WRITE_SIZE_KB_per_launch"]
+out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+out["algorithmic_bytes_per_launch"] = 16 * 512 ** 3
+out["note"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes"
+json.dump(out, open(f"{O}/traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv
+head -5 $O/kernel_stats.csv
+tail -1 $O/stats.log
