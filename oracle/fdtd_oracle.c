@@ -17,12 +17,12 @@
  * order and association of the reference expression; build with -ffp-contract=off
  * and without -ffast-math so that no FMA contraction or re-association happens.
  * Under that contract a serial run is bit-identical to the reference translation
- * unit compiled with g++ -O2 (checked by tests/test_oracle_vs_reference.py when the
- * reference build under oracle/_ref/ is present).
+ * unit compiled with g++ -O2 (checked by tests/test_oracle.py when the reference build
+ * under oracle/_ref/ is present).
  *
  * Pinning: the reference ships no golden vectors for this path.  The restatement is
  * pinned by (a) bit-comparison with the compiled reference (oracle/_ref, built by
- * oracle/build_ref.sh from the sources where they lie) and (b) the fixtures under
+ * oracle/Makefile from the sources where they lie) and (b) the fixtures under
  * tests/golden/ generated from that compiled reference by
  * tests/golden/make_golden.py.
  *
