@@ -175,20 +175,107 @@ __device__ __forceinline__ void st_stream(float *p, float4 v) {
 // Addresses are a wave-uniform plane pointer (scalar registers) plus one 32-bit lane
 // offset per row.
 // ---------------------------------------------------------------------------------
-template <int RY>
-struct MarchSet {
-  float4 col[RY];   // u0, plane x+2 relative to the plane this set is "current" for
-  float4 prev[RY];  // u1 of the current plane
-  float4 med[RY];   // m of the current plane
-  float2 edge[RY];  // z-edge cells of the current plane (first / last lane)
-  float4 halo;      // one row outside the workgroup tile, current plane (loader waves)
+// Storage traits: how the wavefield levels are held in HBM.  A lane always moves 16 bytes of
+// u per row and plane: 4 binary32 cells, or 8 binary16 cells (then a wave row spans 512 cells).
+// m is binary32 in both modes.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct StoreF32 {
+  static constexpr int CELLS = 4;
+  static constexpr int ELEM = 4;
+  typedef f32x4 raw_t;
+  typedef f32x2 edge_t;  // 2 cells
+  static __device__ __forceinline__ void unpack(raw_t v, float (&f)[CELLS]) {
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  static __device__ __forceinline__ raw_t pack(const float (&f)[CELLS]) {
+    raw_t v = {f[0], f[1], f[2], f[3]};
+    return v;
+  }
+  // cells z-2, z-1 (from the previous lane) and z+CELLS, z+CELLS+1 (from the next lane)
+  // eL feeds the first lane (it has no previous lane), eR the last lane
+  static __device__ __forceinline__ void neighbours(raw_t c, edge_t eL, edge_t eR, float &l0, float &l1,
+                                                    float &r0, float &r1) {
+    l0 = dpp_from_prev_lane(eL.x, c.z);
+    l1 = dpp_from_prev_lane(eL.y, c.w);
+    r0 = dpp_from_next_lane(eR.x, c.x);
+    r1 = dpp_from_next_lane(eR.y, c.y);
+  }
+  static __device__ __forceinline__ void edge_values(edge_t e, float &e0, float &e1) { e0 = e.x; e1 = e.y; }
 };
 
-template <int RY, int NW, bool NT, bool FULL>
-__global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs a, int xchunk,
-                                                                     int nzt, int nyt) {
+struct StoreF16 {
+  static constexpr int CELLS = 8;
+  static constexpr int ELEM = 2;
+  typedef u32x4 raw_t;      // 8 packed binary16
+  typedef unsigned edge_t;  // 2 packed binary16
+  static __device__ __forceinline__ float lo(unsigned w) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+  }
+  static __device__ __forceinline__ float hi(unsigned w) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+  }
+  static __device__ __forceinline__ unsigned pk(float a, float b) {  // round to nearest even
+    return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) |
+           ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+  }
+  static __device__ __forceinline__ void unpack(raw_t v, float (&f)[CELLS]) {
+    f[0] = lo(v.x); f[1] = hi(v.x); f[2] = lo(v.y); f[3] = hi(v.y);
+    f[4] = lo(v.z); f[5] = hi(v.z); f[6] = lo(v.w); f[7] = hi(v.w);
+  }
+  static __device__ __forceinline__ raw_t pack(const float (&f)[CELLS]) {
+    raw_t v = {pk(f[0], f[1]), pk(f[2], f[3]), pk(f[4], f[5]), pk(f[6], f[7])};
+    return v;
+  }
+  static __device__ __forceinline__ void neighbours(raw_t c, edge_t eL, edge_t eR, float &l0, float &l1,
+                                                    float &r0, float &r1) {
+    const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)eL, (int)c.w, 0x138, 0xf, 0xf, false);
+    const unsigned r = (unsigned)__builtin_amdgcn_update_dpp((int)eR, (int)c.x, 0x130, 0xf, 0xf, false);
+    l0 = lo(l); l1 = hi(l); r0 = lo(r); r1 = hi(r);
+  }
+  static __device__ __forceinline__ void edge_values(edge_t e, float &e0, float &e1) { e0 = lo(e); e1 = hi(e); }
+};
+
+template <typename ST, int RY>
+struct MarchSet {
+  typename ST::raw_t col[RY];   // u0, plane x+2 relative to the plane this set is "current" for
+  typename ST::raw_t prev[RY];  // u1 of the current plane
+  f32x4 med[RY][ST::CELLS / 4]; // m of the current plane
+  typename ST::edge_t edge[RY]; // z-edge cells of the current plane: (z-2,z-1); full tiles: last lane holds (z+C,z+C+1)
+  typename ST::edge_t edge_r[RY]; // partial tiles only: (z+CELLS, z+CELLS+1) for the last owned lane
+  typename ST::raw_t halo;      // one row outside the workgroup tile, current plane (loader waves)
+};
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_raw(const char *p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
+  else return *reinterpret_cast<const T *>(p);
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void st_raw(char *p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
+  else *reinterpret_cast<T *>(p) = v;
+}
+
+// Level pointers are passed as bytes so that one kernel serves both storage types.
+struct MarchArgs {
+  const char *u0, *u1;
+  char *u2;
+  const char *m;
+  StencilArgs f;  // geometry and coefficients (its pointer members are unused here)
+};
+
+template <typename ST, int RY, int NW, bool NT, bool FULL>
+__global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma, int xchunk, int nzt,
+                                                                     int nyt) {
   constexpr int TY = RY * NW;
-  __shared__ float4 plane[2][TY + 4][64];
+  constexpr int CELLS = ST::CELLS;
+  constexpr int TZ = 64 * CELLS;
+  typedef typename ST::raw_t raw_t;
+  typedef typename ST::edge_t edge_t;
+  __shared__ raw_t plane[2][TY + 4][64];
+  const StencilArgs &a = ma.f;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -199,24 +286,29 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs 
 
   const int yb = a.y_m + yt * TY;  // first row of the workgroup tile
   const int y0 = yb + wave * RY;   // first owned row of this wave
-  const int zfirst = a.z_m + zt * 256 + lane * 4;
-  const bool store_z = FULL ? true : (zfirst <= a.z_M);
-  const int zload = FULL ? zfirst : min(zfirst, a.z_M + 1);
+  const int zfirst = a.z_m + zt * TZ + lane * CELLS;
+  // The z extent is a multiple of CELLS, so a lane owns all of its cells or none.  Full tiles:
+  // one edge load per row serves both ends (lane 63 fetches z+CELLS.., every other lane z-2..).
+  // Partial tiles: lanes behind the last owned one repeat its address, and a second edge load
+  // gives the last owned lane its z+CELLS, z+CELLS+1 (it may also be the first lane).
+  const bool owned = FULL ? true : (zfirst <= a.z_M);
+  const int zload = FULL ? zfirst : min(zfirst, a.z_M - (CELLS - 1));
+  const bool last_owned = (lane == 63) || (!FULL && owned && zfirst + CELLS > a.z_M);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
 
   const Coef k = load_coef(a);
   const unsigned sy = (unsigned)a.sy;
-  const long sxb = a.sx * 4;  // bytes per plane
+  const long sxe = a.sx * ST::ELEM;  // bytes per plane of u
+  const long sxm = a.sx * 4;         // bytes per plane of m
 
-  // 32-bit lane byte offsets inside a plane; rows past y_M+2 repeat a readable row
+  // 32-bit lane offsets (in cells) inside a plane; rows past y_M+2 repeat a readable row
   unsigned voff[RY], veoff[RY];
-  const bool right_edge = (lane == 63) && store_z;
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
     const int y = FULL ? (y0 + r) : min(y0 + r, a.y_M + 2);
-    voff[r] = ((unsigned)(y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO)) * 4u;
-    veoff[r] = right_edge ? voff[r] + 16u : voff[r] - 8u;  // (z+4,z+5) for the last lane, else (z-2,z-1)
+    voff[r] = (unsigned)(y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO);
+    veoff[r] = (FULL && lane == 63) ? voff[r] + CELLS : voff[r] - 2;  // (z+CELLS, z+CELLS+1) or (z-2, z-1)
   }
   // the two waves at each end of the stack also fetch one row outside the tile
   const bool halo_loader = (wave < 2) || (wave >= NW - 2);
@@ -224,54 +316,59 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs 
                                 : (FULL ? yb + TY + (wave - (NW - 2))
                                         : min(yb + TY + (wave - (NW - 2)), a.y_M + 2));
   const int halo_slot = (wave < 2) ? wave : TY + 2 + (wave - (NW - 2));
-  const unsigned vhoff = ((unsigned)(halo_y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO)) * 4u;
+  const unsigned vhoff = (unsigned)(halo_y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO);
 
   // wave-uniform plane pointers of the first plane
-  const char *pu0 = reinterpret_cast<const char *>(a.u0) + (long)(x_begin + FDTD_HALO) * sxb;
-  const char *pu1 = reinterpret_cast<const char *>(a.u1) + (long)(x_begin + FDTD_HALO) * sxb;
-  const char *pm = reinterpret_cast<const char *>(a.m) + (long)(x_begin + FDTD_HALO) * sxb;
-  char *pu2 = reinterpret_cast<char *>(a.u2) + (long)(x_begin + FDTD_HALO) * sxb;
+  const char *pu0 = ma.u0 + (long)(x_begin + FDTD_HALO) * sxe;
+  const char *pu1 = ma.u1 + (long)(x_begin + FDTD_HALO) * sxe;
+  const char *pm = ma.m + (long)(x_begin + FDTD_HALO) * sxm;
+  char *pu2 = ma.u2 + (long)(x_begin + FDTD_HALO) * sxe;
 
-#define LD4(p, off) (*reinterpret_cast<const float4 *>((p) + (off)))
-#define LD4S(p, off) ld_stream<NT>(reinterpret_cast<const float *>((p) + (off)))
-#define LD2(p, off) (*reinterpret_cast<const float2 *>((p) + (off)))
+#define LDU(p, off) ld_raw<false, raw_t>((p) + (size_t)(off) * ST::ELEM)
+#define LDS_(p, off) ld_raw<NT, raw_t>((p) + (size_t)(off) * ST::ELEM)
+#define LDE(p, off) ld_raw<false, edge_t>((p) + (size_t)(off) * ST::ELEM)
+#define LDM(p, off, j) ld_raw<NT, f32x4>((p) + (size_t)(off) * 4 + 16 * (j))
 
-  float4 col[4][RY];  // planes x-2, x-1, x, x+1 of the owned rows
-  MarchSet<RY> sa, sb;
+  raw_t col[4][RY];  // planes x-2, x-1, x, x+1 of the owned rows
+  MarchSet<ST, RY> sa, sb;
 #pragma unroll
   for (int r = 0; r < RY; ++r) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) col[p][r] = LD4(pu0 + (p - 2) * sxb, voff[r]);
-    sa.col[r] = LD4(pu0 + 2 * sxb, voff[r]);
-    sa.prev[r] = LD4S(pu1, voff[r]);
-    sa.med[r] = LD4S(pm, voff[r]);
-    sa.edge[r] = LD2(pu0, veoff[r]);
+    for (int p = 0; p < 4; ++p) col[p][r] = LDU(pu0 + (p - 2) * sxe, voff[r]);
+    sa.col[r] = LDU(pu0 + 2 * sxe, voff[r]);
+    sa.prev[r] = LDS_(pu1, voff[r]);
+#pragma unroll
+    for (int j = 0; j < CELLS / 4; ++j) sa.med[r][j] = LDM(pm, voff[r], j);
+    sa.edge[r] = LDE(pu0, veoff[r]);
+    if (!FULL) sa.edge_r[r] = LDE(pu0, voff[r] + CELLS);
   }
-  sa.halo = make_float4(0.f, 0.f, 0.f, 0.f);
-  sb.halo = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (halo_loader) sa.halo = LD4(pu0, vhoff);
+  sa.halo = raw_t{};
+  sb.halo = raw_t{};
+  if (halo_loader) sa.halo = LDU(pu0, vhoff);
 
   // One plane.  `cur` was loaded during the previous iteration; `nxt` is filled now.
-  auto iteration = [&](int x, int buf, const MarchSet<RY> &cur, MarchSet<RY> &nxt)
+  auto iteration = [&](int x, int buf, const MarchSet<ST, RY> &cur, MarchSet<ST, RY> &nxt)
                        __attribute__((always_inline)) {
     // ---- loads for plane x+1 (repeated on plane x at the end of the chunk) ----
-    const long adv = (x < x_end) ? sxb : 0;
-    const char *q0 = pu0 + adv, *q1 = pu1 + adv, *qm = pm + adv;
+    const bool more = x < x_end;
+    const char *q0 = pu0 + (more ? sxe : 0), *q1 = pu1 + (more ? sxe : 0), *qm = pm + (more ? sxm : 0);
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-      nxt.col[r] = LD4(q0 + 2 * sxb, voff[r]);
-      nxt.prev[r] = LD4S(q1, voff[r]);
-      nxt.med[r] = LD4S(qm, voff[r]);
-      nxt.edge[r] = LD2(q0, veoff[r]);
+      nxt.col[r] = LDU(q0 + 2 * sxe, voff[r]);
+      nxt.prev[r] = LDS_(q1, voff[r]);
+#pragma unroll
+      for (int j = 0; j < CELLS / 4; ++j) nxt.med[r][j] = LDM(qm, voff[r], j);
+      nxt.edge[r] = LDE(q0, veoff[r]);
+      if (!FULL) nxt.edge_r[r] = LDE(q0, voff[r] + CELLS);
     }
-    if (halo_loader) nxt.halo = LD4(q0, vhoff);  // wave-uniform branch
+    if (halo_loader) nxt.halo = LDU(q0, vhoff);  // wave-uniform branch
 
     // ---- publish the centre plane of the owned rows (and the outside row) ----
 #pragma unroll
     for (int r = 0; r < RY; ++r) plane[buf][wave * RY + r + 2][lane] = col[2][r];
     if (halo_loader) plane[buf][halo_slot][lane] = cur.halo;
     __syncthreads();
-    float4 cen[RY + 4];
+    raw_t cen[RY + 4];
     cen[0] = plane[buf][wave * RY + 0][lane];
     cen[1] = plane[buf][wave * RY + 1][lane];
 #pragma unroll
@@ -282,25 +379,44 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs 
     // ---- compute and store plane x ----
 #pragma unroll
     for (int r = 0; r < RY; ++r) {
-      const float4 c = cen[r + 2];
-      const float4 ym2 = cen[r], ym1 = cen[r + 1], yp1 = cen[r + 3], yp2 = cen[r + 4];
-      const float lz = dpp_from_prev_lane(cur.edge[r].x, c.z);
-      const float lw = dpp_from_prev_lane(cur.edge[r].y, c.w);
-      const float rx = dpp_from_next_lane(cur.edge[r].x, c.x);
-      const float ry = dpp_from_next_lane(cur.edge[r].y, c.y);
-      const float4 xm2 = col[0][r], xm1 = col[1][r], xp1 = col[3][r], xp2 = cur.col[r];
-      const float4 up = cur.prev[r], mc = cur.med[r];
-      float4 o;
-      o.x = update_cell(k, c.x, xm2.x, xm1.x, xp1.x, xp2.x, ym2.x, ym1.x, yp1.x, yp2.x, lz, lw,
-                        c.y, c.z, up.x, mc.x);
-      o.y = update_cell(k, c.y, xm2.y, xm1.y, xp1.y, xp2.y, ym2.y, ym1.y, yp1.y, yp2.y, lw, c.x,
-                        c.z, c.w, up.y, mc.y);
-      o.z = update_cell(k, c.z, xm2.z, xm1.z, xp1.z, xp2.z, ym2.z, ym1.z, yp1.z, yp2.z, c.x, c.y,
-                        c.w, rx, up.z, mc.z);
-      o.w = update_cell(k, c.w, xm2.w, xm1.w, xp1.w, xp2.w, ym2.w, ym1.w, yp1.w, yp2.w, c.y, c.z,
-                        rx, ry, up.w, mc.w);
-      if (FULL || (store_z && y0 + r <= a.y_M))
-        st_stream<NT>(reinterpret_cast<float *>(pu2 + voff[r]), o);
+      float c[CELLS], ym2[CELLS], ym1[CELLS], yp1[CELLS], yp2[CELLS];
+      float xm2[CELLS], xm1[CELLS], xp1[CELLS], xp2[CELLS], up[CELLS], mc[CELLS], o[CELLS];
+      ST::unpack(cen[r + 2], c);
+      ST::unpack(cen[r], ym2);
+      ST::unpack(cen[r + 1], ym1);
+      ST::unpack(cen[r + 3], yp1);
+      ST::unpack(cen[r + 4], yp2);
+      ST::unpack(col[0][r], xm2);
+      ST::unpack(col[1][r], xm1);
+      ST::unpack(col[3][r], xp1);
+      ST::unpack(cur.col[r], xp2);
+      ST::unpack(cur.prev[r], up);
+#pragma unroll
+      for (int j = 0; j < CELLS / 4; ++j) {
+        mc[4 * j + 0] = cur.med[r][j].x; mc[4 * j + 1] = cur.med[r][j].y;
+        mc[4 * j + 2] = cur.med[r][j].z; mc[4 * j + 3] = cur.med[r][j].w;
+      }
+      // z-neighbours outside the lane: l0,l1 = z-2,z-1 of cell 0; r0,r1 = z+1,z+2 of the last cell
+      float l0, l1, r0, r1;
+      if (FULL) {
+        ST::neighbours(cen[r + 2], cur.edge[r], cur.edge[r], l0, l1, r0, r1);
+      } else {
+        ST::neighbours(cen[r + 2], cur.edge[r], cur.edge_r[r], l0, l1, r0, r1);
+        float e0, e1;
+        ST::edge_values(cur.edge_r[r], e0, e1);
+        r0 = last_owned ? e0 : r0;
+        r1 = last_owned ? e1 : r1;
+      }
+      float zz[CELLS + 4];
+      zz[0] = l0; zz[1] = l1; zz[CELLS + 2] = r0; zz[CELLS + 3] = r1;
+#pragma unroll
+      for (int i = 0; i < CELLS; ++i) zz[i + 2] = c[i];
+#pragma unroll
+      for (int i = 0; i < CELLS; ++i)
+        o[i] = update_cell(k, c[i], xm2[i], xm1[i], xp1[i], xp2[i], ym2[i], ym1[i], yp1[i], yp2[i],
+                           zz[i], zz[i + 1], zz[i + 3], zz[i + 4], up[i], mc[i]);
+      if (FULL || (owned && y0 + r <= a.y_M))
+        st_raw<NT, raw_t>(pu2 + (size_t)voff[r] * ST::ELEM, ST::pack(o));
     }
 
     // ---- advance: shift the four older planes, step the plane pointers ----
@@ -311,7 +427,7 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs 
       col[2][r] = col[3][r];
       col[3][r] = cur.col[r];
     }
-    pu0 += sxb; pu1 += sxb; pm += sxb; pu2 += sxb;
+    pu0 += sxe; pu1 += sxe; pm += sxm; pu2 += sxe;
   };
 
   for (int x = x_begin; x <= x_end; x += 2) {
@@ -319,9 +435,10 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(StencilArgs 
     if (x + 1 > x_end) break;
     iteration(x + 1, 1, sb, sa);
   }
-#undef LD4
-#undef LD4S
-#undef LD2
+#undef LDU
+#undef LDS_
+#undef LDE
+#undef LDM
 }
 
 // ---------------------------------------------------------------------------------
@@ -489,8 +606,7 @@ static bool geom_valid(const fdtd_geom *g) {
 static bool march_eligible(const fdtd_geom *g, const float *m, const float *u) {
   const int ez = g->z_M - g->z_m + 1;
   return (g->nzp % 4 == 0) && (g->z_m % 4 == 0) && (ez % 4 == 0) &&
-         (g->z_M + 8 <= g->nzp - 1) && (((uintptr_t)m | (uintptr_t)u) % 16 == 0) &&
-         (((long)g->nxp * g->nyp * g->nzp) % 4 == 0);
+         (((uintptr_t)m | (uintptr_t)u) % 16 == 0) && (((long)g->nxp * g->nyp * g->nzp) % 4 == 0);
 }
 
 static StencilArgs make_args(const fdtd_geom *g, const float *m, float *u, int t0, int t1, int t2) {
@@ -540,21 +656,46 @@ static int pick_xchunk(int ex, long tiles_per_chunk) {
   return xchunk;
 }
 
-template <int RY, int NW, bool NT>
-static void launch_march_lds(const StencilArgs &a, hipStream_t s) {
+template <typename ST, int RY, int NW, bool NT>
+static void launch_march_lds(const StencilArgs &a, const void *u0, const void *u1, void *u2, hipStream_t s) {
+  constexpr int TZ = 64 * ST::CELLS;
   const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
-  const int nzt = (ez + 255) / 256;
+  const int nzt = (ez + TZ - 1) / TZ;
   const int nyt = (ey + NW * RY - 1) / (NW * RY);
   const int xchunk = pick_xchunk(ex, (long)nzt * nyt);
   const int nxc = (ex + xchunk - 1) / xchunk;
   const long nblocks = (long)nzt * nyt * nxc;
-  const bool full = (ez % 256 == 0) && (ey % (NW * RY) == 0);
+  MarchArgs ma;
+  ma.u0 = (const char *)u0; ma.u1 = (const char *)u1; ma.u2 = (char *)u2; ma.m = (const char *)a.m;
+  ma.f = a;
+  const bool full = (ez % TZ == 0) && (ey % (NW * RY) == 0);
   if (full)
-    hipLaunchKernelGGL((stencil_march_lds_kernel<RY, NW, NT, true>), dim3((unsigned)nblocks), dim3(NW * 64),
-                       0, s, a, xchunk, nzt, nyt);
+    hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, true>), dim3((unsigned)nblocks),
+                       dim3(NW * 64), 0, s, ma, xchunk, nzt, nyt);
   else
-    hipLaunchKernelGGL((stencil_march_lds_kernel<RY, NW, NT, false>), dim3((unsigned)nblocks), dim3(NW * 64),
-                       0, s, a, xchunk, nzt, nyt);
+    hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, false>), dim3((unsigned)nblocks),
+                       dim3(NW * 64), 0, s, ma, xchunk, nzt, nyt);
+}
+
+template <typename ST>
+static int launch_march_any(const StencilArgs &a, const void *u0, const void *u1, void *u2, hipStream_t s) {
+  // rows per wave x waves per workgroup.  Measured fastest at 512^3: 2 x 8 for binary32 storage;
+  // binary16 storage moves 8 cells per lane (twice the registers per row), so 1 x 8 there.
+  const int ry = env_int("FDTD_MARCH_RY", ST::CELLS == 4 ? 2 : 1), nw = env_int("FDTD_MARCH_NW", 8);
+  const bool nt = env_int("FDTD_NT", 1) != 0;  // non-temporal hints on u1, m, u2
+#define FDTD_TRY(RY_, NW_)                                                              \
+  if (ry == RY_ && nw == NW_) {                                                         \
+    nt ? launch_march_lds<ST, RY_, NW_, true>(a, u0, u1, u2, s)                         \
+       : launch_march_lds<ST, RY_, NW_, false>(a, u0, u1, u2, s);                       \
+    return 0;                                                                           \
+  }
+  FDTD_TRY(2, 8)
+  FDTD_TRY(1, 8)
+  FDTD_TRY(1, 16)
+  FDTD_TRY(4, 4)
+  FDTD_TRY(2, 4)
+#undef FDTD_TRY
+  return (int)hipErrorInvalidValue;
 }
 
 extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, float *u, int t0,
@@ -571,7 +712,8 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
     // and the one-cell-per-thread kernel (most workgroups, no prologue) wins; from 192^3 on
     // the marching kernel does.
     const long cells = (long)ex * ey * ez;
-    variant = (march_eligible(g, m, u) && cells >= 6000000L) ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
+    variant = (march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000))
+                  ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
   }
   if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) &&
       !march_eligible(g, m, u))
@@ -613,13 +755,8 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
       break;
     }
     case FDTD_VARIANT_MARCH: {
-      // rows per wave x waves per workgroup; 2 x 8 measured fastest at 512^3
-      const int ry = env_int("FDTD_MARCH_RY", 2), nw = env_int("FDTD_MARCH_NW", 8);
-      const bool nt = env_int("FDTD_NT", 1) != 0;  // non-temporal hints on u1, m, u2
-      if (ry == 2 && nw == 8) nt ? launch_march_lds<2, 8, true>(a, s) : launch_march_lds<2, 8, false>(a, s);
-      else if (ry == 4 && nw == 4) nt ? launch_march_lds<4, 4, true>(a, s) : launch_march_lds<4, 4, false>(a, s);
-      else if (ry == 2 && nw == 4) nt ? launch_march_lds<2, 4, true>(a, s) : launch_march_lds<2, 4, false>(a, s);
-      else return (int)hipErrorInvalidValue;
+      const int rc = launch_march_any<StoreF32>(a, a.u0, a.u1, a.u2, s);
+      if (rc) return rc;
       break;
     }
     default:
@@ -769,6 +906,15 @@ extern "C" int fdtd_hip_stencil_step_h16(const struct fdtd_geom *g, const float 
   h.u0 = u + (long)t0 * vol;
   h.u1 = u + (long)t1 * vol;
   h.u2 = u + (long)t2 * vol;
+  // marching kernel when every lane can move 8 whole cells with aligned accesses
+  const bool march_ok = (g->nzp % 4 == 0) && (g->z_m % 8 == 0) && (ez % 8 == 0) &&
+                        (((uintptr_t)m | (uintptr_t)u_h16) % 16 == 0) && (vol % 8 == 0) &&
+                        ((long)ex * ey * ez >= env_int("FDTD_MARCH_MIN_CELLS", 6000000));
+  if (march_ok) {
+    const int rc = launch_march_any<StoreF16>(h.f, h.u0, h.u1, h.u2, (hipStream_t)stream);
+    if (rc) return rc;
+    return (int)hipGetLastError();
+  }
   dim3 grid((ez + 63) / 64, (ey + 3) / 4, ex);
   hipLaunchKernelGGL(stencil_naive_h16_kernel, grid, dim3(64, 4, 1), 0, (hipStream_t)stream, h);
   return (int)hipGetLastError();

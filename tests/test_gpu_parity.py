@@ -20,7 +20,10 @@ L2_GATE = 1e-4  # north-star parity gate, L2 as main.cpp:593 defines it
 
 @pytest.mark.parametrize("op", OPERATORS)
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_operator_matches_golden(pkg, hiplib, op, name):
+def test_operator_matches_golden(pkg, hiplib, op, name, monkeypatch):
+    # the fast operator picks its kernel by problem size; force the marching kernel here so that
+    # every case whose shape allows it runs through it (others fall back to the naive kernel)
+    monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0")
     c = cases.build(name, pkg)
     rc, prof = pkg.run_operator(getattr(hiplib, op), c["m"], c["src"], c["coords"], c["u"], **c["kw"])
     assert rc == 0
@@ -34,7 +37,7 @@ def test_operator_matches_golden(pkg, hiplib, op, name):
 
 
 @pytest.mark.parametrize("variant,ry,nw", [("flat", 0, 0), ("naive", 0, 0), ("vec", 0, 0), ("tile3d", 0, 0),
-                                           ("march", 2, 8), ("march", 4, 4), ("march", 2, 4)])
+                                           ("march", 2, 8), ("march", 4, 4), ("march", 2, 4), ("march", 1, 8), ("march", 1, 16)])
 @pytest.mark.parametrize("nt", ["0", "1"])
 def test_variants_and_tile_shapes(pkg, hiplib, variant, ry, nw, nt, monkeypatch):
     """Every stencil variant (and every rows-per-wave x waves-per-workgroup shape of the marching
@@ -170,28 +173,59 @@ def test_run_wrappers(pkg, hiplib):
         assert prof.section0 > 0
 
 
-def test_fp16_storage_mode(pkg, hiplib):
+def fp16_emulation(ob, u, m, src, coords, n, nt, h):
+    """The oracle stepped with a round-to-binary16 after every store (stencil and scatter)."""
+    ue = u.copy()
+    bounds = (0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1)
+    hh = tuple(np.float32(v) for v in h)
+    for t in range(nt):
+        t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
+        ob.oracle_stencil_step(m, ue, bounds, np.float32(1e-3), hh, t0, t1, t2)
+        ue[t2] = ue[t2].astype(np.float16).astype(np.float32)
+        if src is not None:
+            ob.oracle_source_inject(m, src, coords, ue, bounds, hh, (0.0, 0.0, 0.0), (0, src.shape[1] - 1), t, t2)
+            ue[t2] = ue[t2].astype(np.float16).astype(np.float32)
+    return ue
+
+
+@pytest.mark.parametrize("shape,march,ry,nw", [((64, 64, 64), False, 0, 0),      # small grid: one-cell-per-thread kernel
+                                               ((12, 40, 200), True, 1, 8),      # marching kernel, partial tiles
+                                               ((10, 16, 512), True, 1, 8),      # marching kernel, full tiles
+                                               ((10, 32, 512), True, 1, 16),
+                                               ((9, 36, 264), True, 2, 4)])
+def test_fp16_storage_mode(pkg, hiplib, shape, march, ry, nw, monkeypatch):
     """fp16 storage / fp32 compute on the Ricker benchmark inputs (|u| <= 0.12).  Checked two
     ways: bit-exact against the oracle stepped with a round-to-binary16 after every store, and
     the L2 distance to the fp32 oracle reported against its own tolerance (fp16 keeps 11
     significant bits; the leapfrog recursion feeds the rounding back every step)."""
-    n, nt = 64, 50
-    u, m, src, coords = pkg.standard_inputs(n, n, n, nt, 1)
+    nt = 30
+    monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0" if march else "2000000000")
+    if march:
+        monkeypatch.setenv("FDTD_MARCH_RY", str(ry))
+        monkeypatch.setenv("FDTD_MARCH_NW", str(nw))
+    u, m, src, coords = pkg.standard_inputs(*shape, nt, 2)
     u32 = u.copy()
     ob.run_oracle(m, src, coords, u32)
-    # emulation: fp32 arrays whose stored values are always binary16-representable
-    ue = u.copy()
-    bounds = (0, n - 1, 0, n - 1, 0, n - 1)
-    h = (np.float32(0.1),) * 3
-    for t in range(nt):
-        t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
-        ob.oracle_stencil_step(m, ue, bounds, np.float32(1e-3), h, t0, t1, t2)
-        ue[t2] = ue[t2].astype(np.float16).astype(np.float32)
-        ob.oracle_source_inject(m, src, coords, ue, bounds, h, (0.0, 0.0, 0.0), (0, 0), t, t2)
-        ue[t2] = ue[t2].astype(np.float16).astype(np.float32)
+    ue = fp16_emulation(ob, u, m, src, coords, shape, nt, (0.1, 0.1, 0.1))
     rc, prof = pkg.run_operator(hiplib.Kernel_HIP_FP16Storage, m, src, coords, u)
     assert rc == 0 and prof.section0 > 0
     assert ob.bits_equal(u, ue)
     p = pkg.compare_fields(u, u32)
-    print(f"fp16-storage vs fp32 oracle: L2={p.l2:.3e} max_abs={p.max_abs:.3e}")
+    print(f"fp16-storage vs fp32 oracle {shape}: L2={p.l2:.3e} max_abs={p.max_abs:.3e}")
     assert p.nan_count == 0 and p.l2 < 5e-2
+
+
+def test_fp16_storage_random_field(pkg, hiplib, monkeypatch):
+    """fp16 storage on a non-trivial wavefield with varying m and anisotropic spacing: bit-exact
+    against the emulation (values pre-rounded to binary16 so that the upload is lossless)."""
+    monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0")
+    c = cases.build("tile_edges_100", pkg)          # 12 x 100 x 260: z extent 260 is not a multiple of 8
+    c2 = cases.build("full_tiles_256", pkg)         # 11 x 32 x 256
+    for case in (c, c2):
+        u = case["u"].astype(np.float16).astype(np.float32)
+        nt = case["src"].shape[0]
+        shape = tuple(d - 8 for d in u.shape[1:])
+        ue = fp16_emulation(ob, u, case["m"], case["src"], case["coords"], shape, nt, case["kw"]["h"])
+        rc, _ = pkg.run_operator(hiplib.Kernel_HIP_FP16Storage, case["m"], case["src"], case["coords"], u, **case["kw"])
+        assert rc == 0
+        assert ob.bits_equal(u, ue)

@@ -138,6 +138,26 @@ int main(int argc, char **argv) {
     printf("%-7s %dx%dx%d avg %.4f ms (%.1f Gcell/s, %.0f GB/s = %.1f%% of 8 TB/s)  best %.4f ms (%.0f GB/s)\n", names[v], nx, ny, nz, avg,
            cells / avg / 1e6, cells * 16 / avg / 1e6, cells * 16 / avg / 1e6 / 80.0, best, cells * 16 / best / 1e6);
   }
+  if (getenv("KBENCH_H16")) {
+    // binary16 storage: reuse the first half of the u allocation as __half[3][vol]
+    void *uh = (void *)u;
+    // any finite data: m (vol floats) converted into each of the three half levels
+    for (int l = 0; l < 3; ++l) fdtd_hip_convert_f32_to_h16(m, (char *)uh + (size_t)l * vol * 2, vol, 0);
+    for (int w = 0; w < 3; ++w) fdtd_hip_stencil_step_h16(&g, m, uh, w % 3, (w + 2) % 3, (w + 1) % 3, 0);
+    CK(hipDeviceSynchronize());
+    float sum = 0, best = 1e9;
+    for (int r = 0; r < reps; ++r) {
+      CK(hipEventRecord(e0, 0));
+      int rc = fdtd_hip_stencil_step_h16(&g, m, uh, r % 3, (r + 2) % 3, (r + 1) % 3, 0);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      if (rc) { printf("rc=%d\n", rc); return 1; }
+      float t; CK(hipEventElapsedTime(&t, e0, e1)); sum += t; if (t < best) best = t;
+    }
+    float avg = sum / reps;
+    printf("h16     %dx%dx%d avg %.4f ms (%.1f Gcell/s, %.0f GB/s at 10 B/cell = %.1f%% of 8 TB/s)  best %.4f ms\n", nx, ny, nz,
+           avg, cells / avg / 1e6, cells * 10 / avg / 1e6, cells * 10 / avg / 1e6 / 80.0, best);
+  }
   if (getenv("KBENCH_STREAM_SWEEP")) {
     size_t n4 = vol / 4;
     const f32x4 *a = (const f32x4 *)u, *b = (const f32x4 *)(u + vol), *c = (const f32x4 *)m;
