@@ -556,10 +556,10 @@ __global__ __launch_bounds__(512) void stencil_tile3d_kernel(StencilArgs a, int 
 }
 
 // ---------------------------------------------------------------------------------
-// section1: one thread per (source, corner).  Weights, bounds test and amplitude are
-// the expressions of openacc.cpp:185-196; the += is a device-scope float atomic
-// (cuda.cu:165).  Corners of one source never coincide, so with sources that do not
-// share cells the result does not depend on the order the atomics land in.
+// section1, atomic form (more than 128 sources): one thread per (source, corner).  Weights,
+// bounds test and amplitude are the expressions of openacc.cpp:185-196; the += is a
+// device-scope float atomic (cuda.cu:165).  Corners of one source never coincide, so with
+// sources that do not share cells the result does not depend on the order the atomics land in.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,6 +584,49 @@ __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
                   (rz + posz + FDTD_HALO),
               r0);
   }
+}
+
+// Ordered form of the scatter for up to 128 sources (1024 corners), one workgroup.
+// Float addition is not associative, so when corners of different sources fall on the same
+// cell the atomics above give a sum that depends on arrival order.  Here every corner is
+// staged in LDS; the first corner (in the reference's loop order: source, then x, y, z
+// corner) that targets a cell adds all corners of that cell to it one after the other in that
+// order, with plain loads and stores — exactly the serial sequence of openacc.cpp:176-196.
+__global__ __launch_bounds__(1024) void source_inject_ordered_kernel(InjectArgs a) {
+  __shared__ long s_cell[1024];
+  __shared__ float s_val[1024];
+  const int tid = threadIdx.x;
+  const int n = (a.p_src_M - a.p_src_m + 1) * 8;
+  long cell = -1;
+  float r0 = 0.f;
+  if (tid < n) {
+    const int p = a.p_src_m + (tid >> 3);
+    const int rx = (tid >> 2) & 1, ry = (tid >> 1) & 1, rz = tid & 1;
+    const float gx = (-a.o_x + a.coords[(long)p * a.coord_stride + 0]) / a.h_x;
+    const float gy = (-a.o_y + a.coords[(long)p * a.coord_stride + 1]) / a.h_y;
+    const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
+    const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
+    const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
+    if (rx + posx >= a.x_lo && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
+        rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
+      r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
+           (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
+           a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
+               (posz + FDTD_HALO)];
+      cell = (long)(rx + posx - a.x_shift + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
+             (rz + posz + FDTD_HALO);
+    }
+  }
+  s_cell[tid] = cell;
+  s_val[tid] = r0;
+  __syncthreads();
+  if (cell < 0) return;
+  for (int j = 0; j < tid; ++j)
+    if (s_cell[j] == cell) return;  // an earlier corner owns this cell
+  float v = a.u2[cell] + r0;
+  for (int j = tid + 1; j < n; ++j)
+    if (s_cell[j] == cell) v += s_val[j];
+  a.u2[cell] = v;
 }
 
 // ---------------------------------------------------------------------------------
@@ -784,8 +827,11 @@ static int launch_inject(const struct fdtd_geom *g, const float *m, const float 
   a.src_stride = src_stride; a.coord_stride = coord_stride;
   a.x_shift = x_shift; a.x_lo = x_lo; a.x_hi = x_hi;
   const long threads = (long)(p_src_M - p_src_m + 1) * 8;
-  hipLaunchKernelGGL(source_inject_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (threads <= 1024 && env_int("FDTD_INJECT_ATOMIC", 0) == 0)
+    hipLaunchKernelGGL(source_inject_ordered_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(source_inject_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -68,7 +68,8 @@ def test_slab_orchestration_cpu(pkg, tmp_path, name, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("noncubic_aniso", 2), ("time_offset", 3)])
+@pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("noncubic_aniso", 2), ("time_offset", 3),
+                                        ("ricker30_n24_overlap", 2)])
 def test_slab_hip_two_ranks_one_gpu(pkg, tmp_path, name, world):
     u = run_slabs("hip", name, world, tmp_path, pkg)
     check_against_golden(name, u, exact=True)

@@ -93,6 +93,12 @@ __global__ __launch_bounds__(256) void read3_u(const f32x4 *a, const f32x4 *b, c
   }
   if (acc.x == 123.456f) d[0] = acc;
 }
+__global__ void count_diff(const unsigned *a, const unsigned *b, size_t n, unsigned long long *out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    c += (a[i] != b[i]);
+  if (c) atomicAdd(out, c);
+}
 __global__ void fill(float *p, size_t n, unsigned seed) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -137,6 +143,27 @@ int main(int argc, char **argv) {
     float avg = sum / reps;
     printf("%-7s %dx%dx%d avg %.4f ms (%.1f Gcell/s, %.0f GB/s = %.1f%% of 8 TB/s)  best %.4f ms (%.0f GB/s)\n", names[v], nx, ny, nz, avg,
            cells / avg / 1e6, cells * 16 / avg / 1e6, cells * 16 / avg / 1e6 / 80.0, best, cells * 16 / best / 1e6);
+  }
+  if (getenv("KBENCH_VERIFY")) {
+    // large-grid consistency: the marching kernel against the naive kernel, bit for bit, on level 2
+    float *ref; unsigned long long *cnt, h = 0;
+    CK(hipMalloc(&ref, vol * sizeof(float)));
+    CK(hipMalloc(&cnt, 8));
+    CK(hipMemset(cnt, 0, 8));
+    fdtd_hip_stencil_step(&g, m, u, 0, 1, 2, FDTD_VARIANT_NAIVE, 0);
+    CK(hipMemcpy(ref, u + 2 * vol, vol * sizeof(float), hipMemcpyDeviceToDevice));
+    CK(hipMemset(u + 2 * vol, 0xff, vol * sizeof(float)));
+    fdtd_hip_stencil_step(&g, m, u, 0, 1, 2, FDTD_VARIANT_MARCH, 0);
+    // halo cells of level 2 were overwritten by the memset in this check; compare interior rows only
+    // by re-running the naive kernel into the same poisoned buffer layout
+    CK(hipMemcpy(ref, u + 2 * vol, vol * sizeof(float), hipMemcpyDeviceToDevice));
+    CK(hipMemset(u + 2 * vol, 0xff, vol * sizeof(float)));
+    fdtd_hip_stencil_step(&g, m, u, 0, 1, 2, FDTD_VARIANT_NAIVE, 0);
+    count_diff<<<4096, 256>>>((const unsigned *)ref, (const unsigned *)(u + 2 * vol), vol, cnt);
+    CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+    printf("verify %dx%dx%d (%zu cells per level): march vs naive differing words = %llu\n", nx, ny, nz, vol, h);
+    CK(hipFree(ref)); CK(hipFree(cnt));
+    if (h) return 2;
   }
   if (getenv("KBENCH_H16")) {
     // binary16 storage: reuse the first half of the u allocation as __half[3][vol]
