@@ -671,53 +671,75 @@ static StencilArgs make_args(const fdtd_geom *g, const float *m, float *u, int t
   return a;
 }
 
-static int pick_xchunk(int ex, long tiles_per_chunk) {
-  // The marching kernel keeps one workgroup per CU resident, so the grid runs in rounds of
-  // 256 workgroups.  Pick the number of x-chunks that wastes the least of the last round;
-  // among equals prefer fewer, longer chunks (each chunk re-reads 4 planes of u0 to prime
-  // its register column, and one round of workgroups marching in step is what lets
-  // neighbouring tiles find each other's rows in L2).  Never below 8 planes per chunk.
-  int xchunk = env_int("FDTD_XCHUNK", 0);
-  if (xchunk <= 0) {
-    const long cus = 256;
-    long best_chunks = 1;
-    double best_score = -1.0;
-    const long max_chunks = ex / 8 > 0 ? ex / 8 : 1;
-    for (long chunks = 1; chunks <= max_chunks && chunks <= 64; ++chunks) {
-      const long blocks = chunks * tiles_per_chunk;
-      const long rounds = (blocks + cus - 1) / cus;
-      const double fill = (double)blocks / (double)(rounds * cus);
-      const long planes = (ex + chunks - 1) / chunks;
-      const double prologue = (double)planes / (double)(planes + 4);  // useful share of u0 plane loads
-      const double score = fill * (0.75 + 0.25 * prologue);
-      if (score > best_score + 1e-9) { best_score = score; best_chunks = chunks; }
-    }
-    xchunk = (int)((ex + best_chunks - 1) / best_chunks);
+// Launch shape of the marching kernel: `chunks` x-chunks of `xchunk` planes per launch.
+//
+// The kernel keeps one workgroup per CU resident, so a launch runs in rounds of 256 workgroups,
+// and it is fastest when the workgroups of a launch advance plane by plane together (tiles then
+// find their neighbours' rows in L2).  Measured on MI355X: marches longer than ~128 planes drift
+// apart (1024^3 in one launch: 294 Gcell/s; as 16 launches of 64 planes: 343), so long grids are
+// cut into several launches.  Among the candidates the score prefers full rounds, then longer
+// chunks (each chunk re-reads 4 planes of u0 to prime its register column).
+struct MarchShape {
+  int xchunk, chunks;
+};
+static MarchShape pick_march_shape(int ex, long tiles_per_plane) {
+  MarchShape ms;
+  const int forced = env_int("FDTD_XCHUNK", 0);
+  if (forced > 0) {
+    ms.xchunk = forced > ex ? ex : forced;
+    ms.chunks = env_int("FDTD_CHUNKS_PER_LAUNCH", (ex + ms.xchunk - 1) / ms.xchunk);
+    return ms;
   }
-  if (xchunk > ex) xchunk = ex;
-  if (xchunk < 1) xchunk = 1;
-  return xchunk;
+  const long cus = 256;
+  // planes with many tiles (>= ~100) run several rounds per launch and prefer shorter marches
+  const int lcap = env_int("FDTD_MARCH_LCAP", tiles_per_plane >= 100 ? 64 : 128);
+  double best_score = -1.0;
+  ms.xchunk = ex < lcap ? ex : lcap;
+  ms.chunks = 1;
+  for (int c = 1; c <= 64; ++c) {
+    int xc = (ex + c - 1) / c;
+    if (xc > lcap) xc = lcap;
+    if (xc < 8 && c > 1) break;
+    const long blocks = (long)c * tiles_per_plane;
+    const long rounds = (blocks + cus - 1) / cus;
+    const double fill = (double)blocks / (double)(rounds * cus);
+    const double prologue = (double)xc / (double)(xc + 4);  // useful share of u0 plane loads
+    const double score = fill * (0.75 + 0.25 * prologue);
+    if (score > best_score + 1e-9) { best_score = score; ms.xchunk = xc; ms.chunks = c; }
+  }
+  // even out the launches
+  const long per_launch = (long)ms.chunks * ms.xchunk;
+  const long launches = (ex + per_launch - 1) / per_launch;
+  const long planes = (ex + launches - 1) / launches;
+  ms.xchunk = (int)((planes + ms.chunks - 1) / ms.chunks);
+  if (ms.xchunk < 1) ms.xchunk = 1;
+  return ms;
 }
 
 template <typename ST, int RY, int NW, bool NT>
-static void launch_march_lds(const StencilArgs &a, const void *u0, const void *u1, void *u2, hipStream_t s) {
+static void launch_march_lds(const StencilArgs &a0, const void *u0, const void *u1, void *u2, hipStream_t s) {
   constexpr int TZ = 64 * ST::CELLS;
-  const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
+  const int ex = a0.x_M - a0.x_m + 1, ey = a0.y_M - a0.y_m + 1, ez = a0.z_M - a0.z_m + 1;
   const int nzt = (ez + TZ - 1) / TZ;
   const int nyt = (ey + NW * RY - 1) / (NW * RY);
-  const int xchunk = pick_xchunk(ex, (long)nzt * nyt);
-  const int nxc = (ex + xchunk - 1) / xchunk;
-  const long nblocks = (long)nzt * nyt * nxc;
-  MarchArgs ma;
-  ma.u0 = (const char *)u0; ma.u1 = (const char *)u1; ma.u2 = (char *)u2; ma.m = (const char *)a.m;
-  ma.f = a;
+  const MarchShape ms = pick_march_shape(ex, (long)nzt * nyt);
   const bool full = (ez % TZ == 0) && (ey % (NW * RY) == 0);
-  if (full)
-    hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, true>), dim3((unsigned)nblocks),
-                       dim3(NW * 64), 0, s, ma, xchunk, nzt, nyt);
-  else
-    hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, false>), dim3((unsigned)nblocks),
-                       dim3(NW * 64), 0, s, ma, xchunk, nzt, nyt);
+  MarchArgs ma;
+  ma.u0 = (const char *)u0; ma.u1 = (const char *)u1; ma.u2 = (char *)u2; ma.m = (const char *)a0.m;
+  ma.f = a0;
+  const long per_launch = (long)ms.chunks * ms.xchunk;
+  for (long x0 = a0.x_m; x0 <= a0.x_M; x0 += per_launch) {
+    ma.f.x_m = (int)x0;
+    ma.f.x_M = (int)((x0 + per_launch - 1 < a0.x_M) ? x0 + per_launch - 1 : a0.x_M);
+    const int nxc = (ma.f.x_M - ma.f.x_m + ms.xchunk) / ms.xchunk;
+    const long nblocks = (long)nzt * nyt * nxc;
+    if (full)
+      hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, true>), dim3((unsigned)nblocks),
+                         dim3(NW * 64), 0, s, ma, ms.xchunk, nzt, nyt);
+    else
+      hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, false>), dim3((unsigned)nblocks),
+                         dim3(NW * 64), 0, s, ma, ms.xchunk, nzt, nyt);
+  }
 }
 
 template <typename ST>

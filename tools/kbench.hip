@@ -144,6 +144,53 @@ int main(int argc, char **argv) {
     printf("%-7s %dx%dx%d avg %.4f ms (%.1f Gcell/s, %.0f GB/s = %.1f%% of 8 TB/s)  best %.4f ms (%.0f GB/s)\n", names[v], nx, ny, nz, avg,
            cells / avg / 1e6, cells * 16 / avg / 1e6, cells * 16 / avg / 1e6 / 80.0, best, cells * 16 / best / 1e6);
   }
+  if (getenv("KBENCH_FUSE")) {
+    // Prototype of cache-resident time skewing: two time steps are interleaved slab by slab along x
+    // (step t on slab k, then step t+1 on slab k-1) so that the second step finds its operands in the
+    // Infinity Cache.  Reports time per step and checks the result against two plain sweeps.
+    const int S = atoi(getenv("KBENCH_FUSE"));
+    const int T = getenv("KBENCH_FUSE_T") ? atoi(getenv("KBENCH_FUSE_T")) : 2;
+    auto sweep = [&](int time, int lo, int hi) {
+      fdtd_geom gs = g; gs.x_m = lo; gs.x_M = hi;
+      return fdtd_hip_stencil_step(&gs, m, u, time % 3, (time + 2) % 3, (time + 1) % 3, FDTD_VARIANT_MARCH, 0);
+    };
+    auto fused = [&](int time0) {
+      // step s lags step s-1 by one slab
+      const int K = (nx + S - 1) / S;
+      for (int k = 0; k < K + T - 1; ++k)
+        for (int s = 0; s < T; ++s) {
+          const int kk = k - s;
+          if (kk < 0 || kk >= K) continue;
+          const int lo = kk * S, hi = (lo + S - 1 < nx - 1) ? lo + S - 1 : nx - 1;
+          if (sweep(time0 + s, lo, hi)) { printf("sweep failed\n"); exit(1); }
+        }
+    };
+    // correctness: T plain sweeps vs the fused schedule from the same start state
+    float *save, *ref;
+    CK(hipMalloc(&save, 3 * vol * sizeof(float)));
+    CK(hipMalloc(&ref, 3 * vol * sizeof(float)));
+    CK(hipMemcpy(save, u, 3 * vol * sizeof(float), hipMemcpyDeviceToDevice));
+    for (int s = 0; s < T; ++s) sweep(s, 0, nx - 1);
+    CK(hipMemcpy(ref, u, 3 * vol * sizeof(float), hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(u, save, 3 * vol * sizeof(float), hipMemcpyDeviceToDevice));
+    fused(0);
+    unsigned long long *cnt, h = 0;
+    CK(hipMalloc(&cnt, 8)); CK(hipMemset(cnt, 0, 8));
+    count_diff<<<4096, 256>>>((const unsigned *)ref, (const unsigned *)u, 3 * vol, cnt);
+    CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+    printf("fuse T=%d slab=%d: differing words vs plain sweeps = %llu\n", T, S, h);
+    CK(hipFree(save)); CK(hipFree(ref)); CK(hipFree(cnt));
+    for (int w = 0; w < 2; ++w) fused(w * T);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) fused(r * T);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t; CK(hipEventElapsedTime(&t, e0, e1));
+    float per_step = t / (reps * T);
+    printf("fuse T=%d slab=%d: %.4f ms per step (%.1f Gcell/s, %.0f GB/s algorithmic = %.1f%% of 8 TB/s)\n", T, S, per_step,
+           cells / per_step / 1e6, cells * 16 / per_step / 1e6, cells * 16 / per_step / 1e6 / 80.0);
+  }
   if (getenv("KBENCH_VERIFY")) {
     // large-grid consistency: the marching kernel against the naive kernel, bit for bit, on level 2
     float *ref; unsigned long long *cnt, h = 0;
