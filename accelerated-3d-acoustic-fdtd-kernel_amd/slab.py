@@ -169,19 +169,20 @@ class SlabPropagator:
         return self.stepper.mean_interior_kernel_ms()
 
     @classmethod
-    def standard_benchmark(cls, n_per_rank, ny, nz, nt, rank, world, device, variant=-1):
+    def standard_benchmark(cls, n_per_rank, ny, nz, nt, rank, world, device, variant=-1, global_x=0):
         """Weak-scaling benchmark state: global (n_per_rank*world) x ny x nz grid, u = 0, m = 1.5,
         h = 0.1, dt = 1e-3, one Ricker source at a quarter of the global extents
         (main.cpp:285-356 applied to the global grid), built directly on the device."""
         import torch
         import torch.distributed as dist
-        layout = SlabLayout(n_per_rank * world, world)
+        NX = global_x if global_x else n_per_rank * world   # strong scaling: fixed global extent
+        layout = SlabLayout(NX, world)
         nx = layout.nx_loc(rank)
         shape = (nx + 2 * HALO, ny + 2 * HALO, nz + 2 * HALO)
         u = torch.zeros((3,) + shape, dtype=torch.float32, device=device)
         m = torch.full(shape, 1.5, dtype=torch.float32, device=device)
         src = torch.from_numpy(abi.fill_ricker(nt, 1)).to(device)
-        coords = torch.from_numpy(abi.fill_source_coords(1, n_per_rank * world, ny, nz)).to(device)
+        coords = torch.from_numpy(abi.fill_source_coords(1, NX, ny, nz)).to(device)
         stepper = HipStepper(device, variant=variant, time_interior=True)
         comm = TorchComm(dist, rank, world, stepper)
         return cls(layout, rank, u, m, src, coords, dt=1e-3, h=(0.1, 0.1, 0.1), o=(0.0, 0.0, 0.0),
@@ -205,6 +206,7 @@ class HipStepper:
         self.have_ghost_event = False
         self.time_interior = time_interior
         self.timing = []
+        self._geoms = {}
 
     def bind(self, prop):
         self.p = prop
@@ -224,8 +226,11 @@ class HipStepper:
     def stencil(self, x_lo, x_hi, t0, t1, t2, boundary):
         if x_hi < x_lo:
             return
-        g = abi.Geom.from_buffer_copy(self.geom)
-        g.x_m, g.x_M = x_lo, x_hi
+        g = self._geoms.get((x_lo, x_hi))
+        if g is None:
+            g = abi.Geom.from_buffer_copy(self.geom)
+            g.x_m, g.x_M = x_lo, x_hi
+            self._geoms[(x_lo, x_hi)] = g
         timed = self.time_interior and not boundary
         if timed:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
@@ -271,6 +276,7 @@ class TorchComm:
     def __init__(self, dist, rank, world, stepper=None):
         self.dist, self.rank, self.world, self.stepper = dist, rank, world, stepper
         self.backend = dist.get_backend() if world > 1 else None
+        self._ops = {}
 
     def exchange(self, prop, lvl):
         if self.world == 1:
@@ -280,8 +286,8 @@ class TorchComm:
         on_gpu = prop.u.is_cuda
         if on_gpu and self.backend == "nccl":
             torch = st.torch
-            with torch.cuda.stream(st.comm_stream):
-                st.comm_stream.wait_event(st.ev_boundary)
+            ops = self._ops.get(lvl)
+            if ops is None:
                 ops = []
                 if r > 0:
                     ops.append(dist.P2POp(dist.isend, prop.send_left(lvl), r - 1))
@@ -289,6 +295,9 @@ class TorchComm:
                 if r < self.world - 1:
                     ops.append(dist.P2POp(dist.isend, prop.send_right(lvl), r + 1))
                     ops.append(dist.P2POp(dist.irecv, prop.recv_right(lvl), r + 1))
+                self._ops[lvl] = ops
+            with torch.cuda.stream(st.comm_stream):
+                st.comm_stream.wait_event(st.ev_boundary)
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
                 st.ev_ghosts.record(st.comm_stream)

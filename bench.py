@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 ALGO_BYTES_PER_CELL = 16.0     # read u[t0], u[t1], m; write u[t2]; 4 B each
+ALGO_BYTES_PER_CELL_F16 = 10.0  # fp16 storage: u levels 2 B each, m stays 4 B
 
 
 def parse_args():
@@ -34,6 +35,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512, help="cells per axis (per-rank slab thickness for N>1)")
     ap.add_argument("--variant", default="auto", choices=["auto", "flat", "naive", "march", "tile3d", "vec"])
+    ap.add_argument("--storage", default="f32", choices=["f32", "f16"],
+                    help="f16: wavefield levels stored as binary16 in HBM, fp32 arithmetic (config 4; N=1 only)")
+    ap.add_argument("--global-x", type=int, default=0,
+                    help="N>1: total planes along x split over the ranks (strong scaling), instead of --grid planes per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="oracle steps for the CPU baseline sample")
     return ap.parse_args()
@@ -97,7 +102,7 @@ def main():
         slab = pkg.slab
         prop = slab.SlabPropagator.standard_benchmark(n_per_rank=n, ny=n, nz=n, nt=total_steps,
                                                      rank=rank, world=world, device=dev,
-                                                     variant=variant)
+                                                     variant=variant, global_x=args.global_x)
         for t in range(W):
             prop.step(t)
         torch.cuda.synchronize()
@@ -114,7 +119,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         kernel_ms = prop.mean_interior_kernel_ms()
-        cells_per_step = float(n) * n * n * world
+        cells_per_step = float(prop.layout.NX) * n * n
         launch_cells = prop.interior_cells()
         dist.destroy_process_group()
     else:
@@ -128,44 +133,50 @@ def main():
         g = pkg.Geom(npad, npad, npad, 0, n - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
         stream = torch.cuda.current_stream()
         sh = C.c_void_p(stream.cuda_stream)
+        h16 = args.storage == "f16"
+        if h16:
+            u_d = u_d.to(torch.float16)
 
-        def step(t):
-            t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
-            rc = L.fdtd_hip_stencil_step(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), t0, t1, t2, variant, sh)
-            assert rc == 0, rc
-            rc = L.fdtd_hip_source_inject(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(),
-                                          u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
-            assert rc == 0, rc
+        def stencil(t0, t1, t2):
+            if h16:
+                return L.fdtd_hip_stencil_step_h16(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), t0, t1, t2, sh)
+            return L.fdtd_hip_stencil_step(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), t0, t1, t2, variant, sh)
+
+        def inject(t2, t):
+            fn = L.fdtd_hip_source_inject_h16 if h16 else L.fdtd_hip_source_inject
+            return fn(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
 
         for t in range(W):
-            step(t)
+            assert stencil(t % 3, (t + 2) % 3, (t + 1) % 3) == 0
+            assert inject((t + 1) % 3, t) == 0
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         for i, t in enumerate(range(W, total_steps)):
             t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
             ev[i][0].record(stream)
-            rc = L.fdtd_hip_stencil_step(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), t0, t1, t2, variant, sh)
+            rc = stencil(t0, t1, t2)
             ev[i][1].record(stream)
-            rc |= L.fdtd_hip_source_inject(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(),
-                                           u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
+            rc |= inject(t2, t)
             assert rc == 0, rc
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         cells_per_step = float(n) ** 3
         launch_cells = cells_per_step
-        max_u = float(u_d.abs().max().item())
+        max_u = float(u_d.float().abs().max().item())
         assert np.isfinite(max_u) and max_u > 0.0, "field is empty or not finite"
 
     if rank != 0:
         return
 
     mcells = cells_per_step * K / elapsed / 1e6
+    if world == 1 and args.storage == "f16":
+        globals()["ALGO_BYTES_PER_CELL"] = ALGO_BYTES_PER_CELL_F16
     achieved = ALGO_BYTES_PER_CELL * launch_cells / (kernel_ms * 1e-3) / 1e9  # GB/s, dominant kernel
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and world == 1 and n == 512:
+    if os.path.exists(tpath) and world == 1 and n == 512 and args.storage == "f32" and args.variant == "auto":
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
@@ -179,15 +190,15 @@ def main():
         "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (world > 1 and args.global_x) else "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, f16 storage",
         "data": "synthetic",
         "achieved_hbm_GBps_whole_step": round(mcells * ALGO_BYTES_PER_CELL / 1e3, 1),
         "config": {
             "workload": (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
                          f"{total_steps} steps ({W} untimed)" if world == 1 else
-                         f"{n * world}x{n}x{n} fp32 as {world} x-slabs of {n} planes, 2-plane ghost exchange "
+                         f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, 2-plane ghost exchange "
                          f"per step over RCCL, {total_steps} steps ({W} untimed)"),
             "variant": args.variant,
             "bytes_per_cell_update": ALGO_BYTES_PER_CELL,
