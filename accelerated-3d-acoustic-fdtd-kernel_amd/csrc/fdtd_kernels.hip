@@ -244,7 +244,7 @@ struct MarchSet {
   f32x4 med[RY][ST::CELLS / 4]; // m of the current plane
   typename ST::edge_t edge[RY]; // z-edge cells of the current plane: (z-2,z-1); full tiles: last lane holds (z+C,z+C+1)
   typename ST::edge_t edge_r[RY]; // partial tiles only: (z+CELLS, z+CELLS+1) for the last owned lane
-  typename ST::raw_t halo;      // one row outside the workgroup tile, current plane (loader waves)
+  typename ST::raw_t halo;      // one row outside the workgroup tile, plane +2 like col (loader waves)
 };
 
 template <bool NT, typename T>
@@ -342,9 +342,17 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
     sa.edge[r] = LDE(pu0, veoff[r]);
     if (!FULL) sa.edge_r[r] = LDE(pu0, voff[r] + CELLS);
   }
+  // The outside row is fetched for plane x+2 (first iteration) / x+3 (later), i.e. at the same
+  // plane step at which the neighbouring tile fetches it as one of its own rows, so that one of
+  // the two requests hits in L2; it waits in a two-deep queue until its plane is the centre.
   sa.halo = raw_t{};
   sb.halo = raw_t{};
-  if (halo_loader) sa.halo = LDU(pu0, vhoff);
+  raw_t hq0 = raw_t{}, hq1 = raw_t{};  // outside row at planes x, x+1
+  if (halo_loader) {
+    hq0 = LDU(pu0, vhoff);
+    hq1 = LDU(pu0 + sxe, vhoff);
+    sa.halo = LDU(pu0 + 2 * sxe, vhoff);
+  }
 
   // One plane.  `cur` was loaded during the previous iteration; `nxt` is filled now.
   auto iteration = [&](int x, int buf, const MarchSet<ST, RY> &cur, MarchSet<ST, RY> &nxt)
@@ -361,12 +369,12 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
       nxt.edge[r] = LDE(q0, veoff[r]);
       if (!FULL) nxt.edge_r[r] = LDE(q0, voff[r] + CELLS);
     }
-    if (halo_loader) nxt.halo = LDU(q0, vhoff);  // wave-uniform branch
+    if (halo_loader) nxt.halo = LDU(q0 + 2 * sxe, vhoff);  // wave-uniform branch
 
     // ---- publish the centre plane of the owned rows (and the outside row) ----
 #pragma unroll
     for (int r = 0; r < RY; ++r) plane[buf][wave * RY + r + 2][lane] = col[2][r];
-    if (halo_loader) plane[buf][halo_slot][lane] = cur.halo;
+    if (halo_loader) plane[buf][halo_slot][lane] = hq0;
     __syncthreads();
     raw_t cen[RY + 4];
     cen[0] = plane[buf][wave * RY + 0][lane];
@@ -427,6 +435,8 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
       col[2][r] = col[3][r];
       col[3][r] = cur.col[r];
     }
+    hq0 = hq1;
+    hq1 = cur.halo;
     pu0 += sxe; pu1 += sxe; pm += sxm; pu2 += sxe;
   };
 
