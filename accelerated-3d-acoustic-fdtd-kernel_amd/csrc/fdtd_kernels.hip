@@ -266,34 +266,43 @@ struct MarchArgs {
   StencilArgs f;  // geometry and coefficients (its pointer members are unused here)
 };
 
-template <typename ST, int RY, int NW, bool NT, bool FULL>
+// LPR = lanes per row.  With LPR = 64 a wave spans 64*CELLS cells of its RY rows.  With LPR = 32
+// the two halves of a wave work on different row groups of a tile half as wide, so that z
+// extents of 1.5, 2.5, ... full-width tiles (384, 640) still fill every lane; each half then
+// behaves like a narrow wave of its own ("virtual wave" vw below).
+template <typename ST, int RY, int NW, bool NT, bool FULL, int LPR>
 __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma, int xchunk, int nzt,
                                                                      int nyt) {
-  constexpr int TY = RY * NW;
+  constexpr int WR = 64 / LPR;          // row groups side by side in one wave
+  constexpr int NWV = NW * WR;          // virtual waves per workgroup
+  constexpr int TY = RY * NWV;
   constexpr int CELLS = ST::CELLS;
-  constexpr int TZ = 64 * CELLS;
+  constexpr int TZ = LPR * CELLS;
+  constexpr bool EDGE2 = !FULL || WR > 1;  // separate left/right edge loads and explicit selects
   typedef typename ST::raw_t raw_t;
   typedef typename ST::edge_t edge_t;
-  __shared__ raw_t plane[2][TY + 4][64];
+  __shared__ raw_t plane[2][TY + 4][LPR];
   const StencilArgs &a = ma.f;
 
   const int lane = threadIdx.x & 63;
+  const int zl = lane % LPR;            // position along z inside the row group
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int vw = (WR == 1) ? wave : wave * WR + lane / LPR;
   const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int zt = t % nzt;
   const int yt = (t / nzt) % nyt;
   const int xc = t / (nzt * nyt);
 
   const int yb = a.y_m + yt * TY;  // first row of the workgroup tile
-  const int y0 = yb + wave * RY;   // first owned row of this wave
-  const int zfirst = a.z_m + zt * TZ + lane * CELLS;
+  const int y0 = yb + vw * RY;     // first owned row of this (virtual) wave
+  const int zfirst = a.z_m + zt * TZ + zl * CELLS;
   // The z extent is a multiple of CELLS, so a lane owns all of its cells or none.  Full tiles:
   // one edge load per row serves both ends (lane 63 fetches z+CELLS.., every other lane z-2..).
   // Partial tiles: lanes behind the last owned one repeat its address, and a second edge load
   // gives the last owned lane its z+CELLS, z+CELLS+1 (it may also be the first lane).
   const bool owned = FULL ? true : (zfirst <= a.z_M);
   const int zload = FULL ? zfirst : min(zfirst, a.z_M - (CELLS - 1));
-  const bool last_owned = (lane == 63) || (!FULL && owned && zfirst + CELLS > a.z_M);
+  const bool last_owned = (zl == LPR - 1) || (!FULL && owned && zfirst + CELLS > a.z_M);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
 
@@ -308,15 +317,18 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
   for (int r = 0; r < RY; ++r) {
     const int y = FULL ? (y0 + r) : min(y0 + r, a.y_M + 2);
     voff[r] = (unsigned)(y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO);
-    veoff[r] = (FULL && lane == 63) ? voff[r] + CELLS : voff[r] - 2;  // (z+CELLS, z+CELLS+1) or (z-2, z-1)
+    veoff[r] = (!EDGE2 && lane == 63) ? voff[r] + CELLS : voff[r] - 2;  // (z+CELLS, z+CELLS+1) or (z-2, z-1)
   }
-  // the two waves at each end of the stack also fetch one row outside the tile
-  const bool halo_loader = (wave < 2) || (wave >= NW - 2);
-  const int halo_y = (wave < 2) ? yb - 2 + wave
-                                : (FULL ? yb + TY + (wave - (NW - 2))
-                                        : min(yb + TY + (wave - (NW - 2)), a.y_M + 2));
-  const int halo_slot = (wave < 2) ? wave : TY + 2 + (wave - (NW - 2));
+  // the two (virtual) waves at each end of the stack also fetch one row outside the tile;
+  // with WR > 1 that is a per-lane property, so then every lane issues the load (the others
+  // re-read their own row) and only the LDS write is conditional
+  const bool halo_loader = (vw < 2) || (vw >= NWV - 2);
+  const int halo_y = (vw < 2) ? yb - 2 + vw
+                              : ((vw >= NWV - 2) ? min(yb + TY + (vw - (NWV - 2)), a.y_M + 2)
+                                                 : min(y0, a.y_M + 2));
+  const int halo_slot = (vw < 2) ? vw : TY + 2 + (vw - (NWV - 2));
   const unsigned vhoff = (unsigned)(halo_y + FDTD_HALO) * sy + (unsigned)(zload + FDTD_HALO);
+  const bool halo_load = (WR > 1) ? true : halo_loader;
 
   // wave-uniform plane pointers of the first plane
   const char *pu0 = ma.u0 + (long)(x_begin + FDTD_HALO) * sxe;
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
 #pragma unroll
     for (int j = 0; j < CELLS / 4; ++j) sa.med[r][j] = LDM(pm, voff[r], j);
     sa.edge[r] = LDE(pu0, veoff[r]);
-    if (!FULL) sa.edge_r[r] = LDE(pu0, voff[r] + CELLS);
+    if (EDGE2) sa.edge_r[r] = LDE(pu0, voff[r] + CELLS);
   }
   // The outside row is fetched for plane x+2 (first iteration) / x+3 (later), i.e. at the same
   // plane step at which the neighbouring tile fetches it as one of its own rows, so that one of
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
   sa.halo = raw_t{};
   sb.halo = raw_t{};
   raw_t hq0 = raw_t{}, hq1 = raw_t{};  // outside row at planes x, x+1
-  if (halo_loader) {
+  if (halo_load) {
     hq0 = LDU(pu0, vhoff);
     hq1 = LDU(pu0 + sxe, vhoff);
     sa.halo = LDU(pu0 + 2 * sxe, vhoff);
@@ -367,22 +379,22 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
 #pragma unroll
       for (int j = 0; j < CELLS / 4; ++j) nxt.med[r][j] = LDM(qm, voff[r], j);
       nxt.edge[r] = LDE(q0, veoff[r]);
-      if (!FULL) nxt.edge_r[r] = LDE(q0, voff[r] + CELLS);
+      if (EDGE2) nxt.edge_r[r] = LDE(q0, voff[r] + CELLS);
     }
-    if (halo_loader) nxt.halo = LDU(q0 + 2 * sxe, vhoff);  // wave-uniform branch
+    if (halo_load) nxt.halo = LDU(q0 + 2 * sxe, vhoff);  // wave-uniform (WR == 1) or unconditional
 
     // ---- publish the centre plane of the owned rows (and the outside row) ----
 #pragma unroll
-    for (int r = 0; r < RY; ++r) plane[buf][wave * RY + r + 2][lane] = col[2][r];
-    if (halo_loader) plane[buf][halo_slot][lane] = hq0;
+    for (int r = 0; r < RY; ++r) plane[buf][vw * RY + r + 2][zl] = col[2][r];
+    if (halo_loader) plane[buf][halo_slot][zl] = hq0;
     __syncthreads();
     raw_t cen[RY + 4];
-    cen[0] = plane[buf][wave * RY + 0][lane];
-    cen[1] = plane[buf][wave * RY + 1][lane];
+    cen[0] = plane[buf][vw * RY + 0][zl];
+    cen[1] = plane[buf][vw * RY + 1][zl];
 #pragma unroll
     for (int r = 0; r < RY; ++r) cen[r + 2] = col[2][r];
-    cen[RY + 2] = plane[buf][wave * RY + RY + 2][lane];
-    cen[RY + 3] = plane[buf][wave * RY + RY + 3][lane];
+    cen[RY + 2] = plane[buf][vw * RY + RY + 2][zl];
+    cen[RY + 3] = plane[buf][vw * RY + RY + 3][zl];
 
     // ---- compute and store plane x ----
 #pragma unroll
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
       }
       // z-neighbours outside the lane: l0,l1 = z-2,z-1 of cell 0; r0,r1 = z+1,z+2 of the last cell
       float l0, l1, r0, r1;
-      if (FULL) {
+      if (!EDGE2) {
         ST::neighbours(cen[r + 2], cur.edge[r], cur.edge[r], l0, l1, r0, r1);
       } else {
         ST::neighbours(cen[r + 2], cur.edge[r], cur.edge_r[r], l0, l1, r0, r1);
@@ -414,6 +426,11 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
         ST::edge_values(cur.edge_r[r], e0, e1);
         r0 = last_owned ? e0 : r0;
         r1 = last_owned ? e1 : r1;
+        if (WR > 1) {  // the first lane of a row group must not take the other group's cells
+          ST::edge_values(cur.edge[r], e0, e1);
+          l0 = (zl == 0) ? e0 : l0;
+          l1 = (zl == 0) ? e1 : l1;
+        }
       }
       float zz[CELLS + 4];
       zz[0] = l0; zz[1] = l1; zz[CELLS + 2] = r0; zz[CELLS + 3] = r1;
@@ -726,14 +743,15 @@ static MarchShape pick_march_shape(int ex, long tiles_per_plane) {
   return ms;
 }
 
-template <typename ST, int RY, int NW, bool NT>
-static void launch_march_lds(const StencilArgs &a0, const void *u0, const void *u1, void *u2, hipStream_t s) {
-  constexpr int TZ = 64 * ST::CELLS;
+template <typename ST, int RY, int NW, bool NT, int LPR>
+static void launch_march_shape(const StencilArgs &a0, const void *u0, const void *u1, void *u2, hipStream_t s) {
+  constexpr int TZ = LPR * ST::CELLS;
+  constexpr int TY = RY * NW * (64 / LPR);
   const int ex = a0.x_M - a0.x_m + 1, ey = a0.y_M - a0.y_m + 1, ez = a0.z_M - a0.z_m + 1;
   const int nzt = (ez + TZ - 1) / TZ;
-  const int nyt = (ey + NW * RY - 1) / (NW * RY);
+  const int nyt = (ey + TY - 1) / TY;
   const MarchShape ms = pick_march_shape(ex, (long)nzt * nyt);
-  const bool full = (ez % TZ == 0) && (ey % (NW * RY) == 0);
+  const bool full = (ez % TZ == 0) && (ey % TY == 0);
   MarchArgs ma;
   ma.u0 = (const char *)u0; ma.u1 = (const char *)u1; ma.u2 = (char *)u2; ma.m = (const char *)a0.m;
   ma.f = a0;
@@ -744,12 +762,29 @@ static void launch_march_lds(const StencilArgs &a0, const void *u0, const void *
     const int nxc = (ma.f.x_M - ma.f.x_m + ms.xchunk) / ms.xchunk;
     const long nblocks = (long)nzt * nyt * nxc;
     if (full)
-      hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, true>), dim3((unsigned)nblocks),
+      hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, true, LPR>), dim3((unsigned)nblocks),
                          dim3(NW * 64), 0, s, ma, ms.xchunk, nzt, nyt);
     else
-      hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, false>), dim3((unsigned)nblocks),
+      hipLaunchKernelGGL((stencil_march_lds_kernel<ST, RY, NW, NT, false, LPR>), dim3((unsigned)nblocks),
                          dim3(NW * 64), 0, s, ma, ms.xchunk, nzt, nyt);
   }
+}
+
+// Half-width row groups (LPR = 32) are instantiated for the default shape of each storage type only.
+template <typename ST, int RY, int NW, bool NT>
+static void launch_march_lds(const StencilArgs &a, const void *u0, const void *u1, void *u2, hipStream_t s) {
+  constexpr bool has_half = (ST::CELLS == 4 && RY == 2 && NW == 8) || (ST::CELLS == 8 && RY == 1 && NW == 8);
+  if constexpr (has_half) {
+    // a z extent of an odd number of half tiles leaves the last full-width tile at most half used
+    const int ez = a.z_M - a.z_m + 1;
+    const int half = 32 * ST::CELLS;
+    const int lpr = env_int("FDTD_MARCH_LPR", (((ez + half - 1) / half) & 1) ? 32 : 64);
+    if (lpr == 32) {
+      launch_march_shape<ST, RY, NW, NT, 32>(a, u0, u1, u2, s);
+      return;
+    }
+  }
+  launch_march_shape<ST, RY, NW, NT, 64>(a, u0, u1, u2, s);
 }
 
 template <typename ST>

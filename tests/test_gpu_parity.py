@@ -57,6 +57,19 @@ def test_variants_and_tile_shapes(pkg, hiplib, variant, ry, nw, nt, monkeypatch)
         check_against_golden(name, c["u"], exact=True)
 
 
+@pytest.mark.parametrize("lpr", ["32", "64"])
+def test_march_row_group_width(pkg, hiplib, lpr, monkeypatch):
+    """Both lane layouts of the marching kernel (a wave spanning one 256-cell row group, or two
+    128-cell row groups side by side) on every fixture case, fp32 storage."""
+    monkeypatch.setenv("FDTD_VARIANT", "march")
+    monkeypatch.setenv("FDTD_MARCH_LPR", lpr)
+    for name in cases.CASES:
+        c = cases.build(name, pkg)
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
+        assert rc == 0
+        check_against_golden(name, c["u"], exact=True)
+
+
 @pytest.mark.parametrize("xchunk", ["1", "3", "8", "1000"])
 def test_march_x_chunking(pkg, hiplib, xchunk, monkeypatch):
     monkeypatch.setenv("FDTD_VARIANT", "march")
@@ -216,7 +229,8 @@ def fp16_emulation(ob, u, m, src, coords, n, nt, h):
 
 
 @pytest.mark.parametrize("shape,march,ry,nw", [((64, 64, 64), False, 0, 0),      # small grid: one-cell-per-thread kernel
-                                               ((12, 40, 200), True, 1, 8),      # marching kernel, partial tiles
+                                               ((12, 40, 200), True, 1, 8),      # marching kernel, partial tiles (half-width groups)
+                                               ((12, 40, 328), True, 1, 8),      # partial tiles, full-width groups
                                                ((10, 16, 512), True, 1, 8),      # marching kernel, full tiles
                                                ((10, 32, 512), True, 1, 16),
                                                ((9, 36, 264), True, 2, 4)])
