@@ -12,10 +12,14 @@
 // so every variant returns the bits a serial host run of the reference returns.
 //
 // The path is HBM-bound (16 B of compulsory traffic per cell update against ~45
-// VALU operations), so the design work is in the memory system: 16-byte lane
-// accesses, every wave streaming along x with the x-neighbours held in registers,
-// no workgroup barriers, loads for plane x+1 in flight while plane x is computed,
-// and a tile->workgroup map that keeps y-adjacent tiles on one XCD's L2.
+// VALU operations), so the design work is in the memory system.  The default kernel
+// (stencil_march_lds_kernel) uses 16-byte lane accesses, waves that stream along x
+// with the x-neighbours held in registers, z-neighbours from adjacent lanes (DPP),
+// y-neighbours handed between the waves of a workgroup through LDS (one barrier per
+// plane), loads for plane x+1 in flight while plane x is computed, and a
+// tile->workgroup map that keeps y-adjacent tiles on one XCD's L2 and marching in step.
+// The other kernels (flat, naive, vec, tile3d) are the simpler shapes the reference
+// and its north-star name; they serve small or unaligned grids and as measurement points.
 #include "fdtd_device.h"
 
 #pragma clang fp contract(off)
