@@ -826,7 +826,10 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
     // and the one-cell-per-thread kernel (most workgroups, no prologue) wins; from 192^3 on
     // the marching kernel does.
     const long cells = (long)ex * ey * ez;
-    variant = (march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000))
+    // Ranges of fewer than 8 planes (the boundary planes of a slab) would spend more on priming
+    // the register column than on the sweep: naive kernel as well.
+    variant = (march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000) &&
+               ex >= env_int("FDTD_MARCH_MIN_PLANES", 8))
                   ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
   }
   if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) &&
@@ -1026,7 +1029,8 @@ extern "C" int fdtd_hip_stencil_step_h16(const struct fdtd_geom *g, const float 
   // marching kernel when every lane can move 8 whole cells with aligned accesses
   const bool march_ok = (g->nzp % 4 == 0) && (g->z_m % 8 == 0) && (ez % 8 == 0) &&
                         (((uintptr_t)m | (uintptr_t)u_h16) % 16 == 0) && (vol % 8 == 0) &&
-                        ((long)ex * ey * ez >= env_int("FDTD_MARCH_MIN_CELLS", 6000000));
+                        ((long)ex * ey * ez >= env_int("FDTD_MARCH_MIN_CELLS", 6000000)) &&
+                        ex >= env_int("FDTD_MARCH_MIN_PLANES", 8);
   if (march_ok) {
     const int rc = launch_march_any<StoreF16>(h.f, h.u0, h.u1, h.u2, (hipStream_t)stream);
     if (rc) return rc;
