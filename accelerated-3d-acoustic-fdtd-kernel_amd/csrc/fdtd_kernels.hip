@@ -271,9 +271,9 @@ struct MarchArgs {
 };
 
 // LPR = lanes per row.  With LPR = 64 a wave spans 64*CELLS cells of its RY rows.  With LPR = 32
-// the two halves of a wave work on different row groups of a tile half as wide, so that z
-// extents of 1.5, 2.5, ... full-width tiles (384, 640) still fill every lane; each half then
-// behaves like a narrow wave of its own ("virtual wave" vw below).
+// (16) the two halves (four quarters) of a wave work on different row groups of a tile half (a
+// quarter) as wide, so that z extents of 1.5, 2.5, ... full-width tiles (384, 640; 320, 576) still
+// fill every lane; each part then behaves like a narrow wave of its own ("virtual wave" vw below).
 template <typename ST, int RY, int NW, bool NT, bool FULL, int LPR>
 __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma, int xchunk, int nzt,
                                                                      int nyt) {
@@ -734,8 +734,8 @@ static MarchShape pick_march_shape(int ex, long tiles_per_plane) {
     const long blocks = (long)c * tiles_per_plane;
     const long rounds = (blocks + cus - 1) / cus;
     const double fill = (double)blocks / (double)(rounds * cus);
-    const double prologue = (double)xc / (double)(xc + 4);  // useful share of u0 plane loads
-    const double score = fill * (0.75 + 0.25 * prologue);
+    // each chunk re-reads 4 planes of u0 and fills/drains its pipeline: worth ~6 planes of marching
+    const double score = fill * (double)xc / (double)(xc + 6);
     if (score > best_score + 1e-9) { best_score = score; ms.xchunk = xc; ms.chunks = c; }
   }
   // even out the launches
@@ -774,19 +774,25 @@ static void launch_march_shape(const StencilArgs &a0, const void *u0, const void
   }
 }
 
-// Half-width row groups (LPR = 32) are instantiated for the default shape of each storage type only.
+// Narrower row groups (LPR = 32, 16) are instantiated for the default shape of each storage type
+// only: 512 -> 64 lanes per row, 384 or 640 -> 32, 320 or 576 -> 16.
 template <typename ST, int RY, int NW, bool NT>
 static void launch_march_lds(const StencilArgs &a, const void *u0, const void *u1, void *u2, hipStream_t s) {
-  constexpr bool has_half = (ST::CELLS == 4 && RY == 2 && NW == 8) || (ST::CELLS == 8 && RY == 1 && NW == 8);
-  if constexpr (has_half) {
-    // a z extent of an odd number of half tiles leaves the last full-width tile at most half used
+  constexpr bool has_narrow = (ST::CELLS == 4 && RY == 2 && NW == 8) || (ST::CELLS == 8 && RY == 1 && NW == 8);
+  if constexpr (has_narrow) {
     const int ez = a.z_M - a.z_m + 1;
-    const int half = 32 * ST::CELLS;
-    const int lpr = env_int("FDTD_MARCH_LPR", (((ez + half - 1) / half) & 1) ? 32 : 64);
-    if (lpr == 32) {
-      launch_march_shape<ST, RY, NW, NT, 32>(a, u0, u1, u2, s);
-      return;
-    }
+    auto padded = [ez](int lpr) {
+      const long tz = (long)lpr * ST::CELLS;
+      return (ez + tz - 1) / tz * tz;
+    };
+    // 32 lanes per row as soon as it pads less than 64; 16 (more row groups per wave, shorter
+    // contiguous segments) only when it saves another 10 % on an extent of at least one full tile
+    int best = 64;
+    if (padded(32) < padded(64)) best = 32;
+    if (ez >= 64 * ST::CELLS && 10 * padded(16) <= 9 * padded(best)) best = 16;
+    const int lpr = env_int("FDTD_MARCH_LPR", best);
+    if (lpr == 32) { launch_march_shape<ST, RY, NW, NT, 32>(a, u0, u1, u2, s); return; }
+    if (lpr == 16) { launch_march_shape<ST, RY, NW, NT, 16>(a, u0, u1, u2, s); return; }
   }
   launch_march_shape<ST, RY, NW, NT, 64>(a, u0, u1, u2, s);
 }
@@ -805,7 +811,9 @@ static int launch_march_any(const StencilArgs &a, const void *u0, const void *u1
   }
   FDTD_TRY(2, 8)
   FDTD_TRY(1, 8)
-  FDTD_TRY(1, 16)
+  if constexpr (ST::CELLS == 4) {  // 16 waves leave 128 registers each: binary32 storage only
+    FDTD_TRY(1, 16)
+  }
   FDTD_TRY(4, 4)
   FDTD_TRY(2, 4)
 #undef FDTD_TRY
