@@ -37,6 +37,14 @@ CASES = {
                                           bounds=(1, 30, 5, 26, 5, 26))),
     "time_offset": ("random", dict(n=(24, 24, 24), nt=19, nsrc=2, h=(1.0, 1.0, 1.0), seed=16,
                                    time_m=7)),
+    # only sources 1..2 of 4 are active (p_src_m > 0, p_src_M < nsrc-1)
+    "source_subset": ("random", dict(n=(16, 20, 24), nt=8, nsrc=4, h=(1.0, 1.0, 1.0), seed=19, p_src=(1, 2))),
+    # empty update range in x (x_M < x_m): no cell is updated, the scatter test excludes every corner too
+    "empty_range": ("random", dict(n=(12, 12, 16), nt=4, nsrc=1, h=(1.0, 1.0, 1.0), seed=20,
+                                   bounds=(5, 4, 0, 11, 0, 15))),
+    # time_M < time_m: nothing happens at all
+    "zero_steps": ("random", dict(n=(12, 12, 16), nt=4, nsrc=1, h=(1.0, 1.0, 1.0), seed=21, time_m=3,
+                                  time_M_override=2)),
     "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
     "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
 }
@@ -71,6 +79,8 @@ def build(name, pkg):
         kw["bounds"] = p["bounds"]
     if "time_m" in p:
         kw["time_m"] = p["time_m"]
+    if "p_src" in p:
+        kw["p_src"] = p["p_src"]
     src = coords = None
     if nsrc > 0:
         src = _rng_field(rng, (nt, nsrc), -50.0, 50.0)
@@ -83,6 +93,8 @@ def build(name, pkg):
         kw["time_M"] = nt - 1
     else:
         kw["time_M"] = nt - 1
+    if "time_M_override" in p:
+        kw["time_M"] = p["time_M_override"]
     return dict(u=u, m=m, src=src, coords=coords, kw=kw)
 
 
