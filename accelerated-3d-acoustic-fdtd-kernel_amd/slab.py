@@ -11,11 +11,13 @@ run.  What is new is the data movement:
   physical halo.  Every ghost block is one contiguous span of 2*nyp*nzp floats, so no pack or
   unpack kernels exist.  (Cutting along the contiguous z axis instead would turn each ghost
   "plane" into a stride-nzp gather of 2-float pieces.)
-* per step: (1) update the two outermost owned planes on each side, (2) scatter the sources
-  that land there, (3) hand exactly those planes of the new level to the neighbours — two
-  point-to-point messages per neighbour, no collective — on a second stream while (4) the
-  interior planes are updated and (5) the remaining sources are scattered.  The next step's
-  boundary update waits for the messages; its interior update does not.
+* per step, boundary chain: (1) update the two outermost owned planes on each side, (2) scatter
+  the sources that land there, (3) hand exactly those planes of the new level to the
+  neighbours — two point-to-point messages per neighbour, no collective.  Interior chain:
+  (4) update the interior planes, (5) scatter the remaining sources.  The two chains are
+  independent within a step (disjoint planes of the new level) and run on two streams; across
+  steps the boundary chain needs the previous interior update and the previous messages, the
+  interior chain needs the previous boundary update, never the messages.
 * a source corner is applied by the rank that owns its global x index (first/last rank also
   own the physical halo plane next to them, openacc.cpp:192), so each corner is added once.
 
@@ -100,7 +102,8 @@ class SlabPropagator:
         lo, hi = layout.owned_corner_range(rank)
         # regions of owned scatter targets: left boundary, right boundary, interior (global x)
         nx, xo = self.nx, self.x_off
-        self.overlap = layout.world > 1 and nx >= 2 * GHOST + 1
+        exchanging = layout.world > 1 or getattr(comm, "has_neighbours", False)
+        self.overlap = exchanging and nx >= 2 * GHOST + 1
         if self.overlap:
             self.regions = {
                 "left": (lo, xo + GHOST - 1),
@@ -124,20 +127,22 @@ class SlabPropagator:
         st, nx = self.stepper, self.nx
         st.begin_step()
         if self.overlap:
+            # the long chain is issued first so that it never queues behind the short one
+            st.stencil(GHOST, nx - GHOST - 1, t0, t1, t2, boundary=False)
+            if self.active["interior"]:
+                st.inject(self.regions["interior"], t2, time, boundary=False)
+            st.interior_done()
             st.stencil(0, GHOST - 1, t0, t1, t2, boundary=True)
             st.stencil(nx - GHOST, nx - 1, t0, t1, t2, boundary=True)
             for k in ("left", "right"):
                 if self.active[k]:
-                    st.inject(self.regions[k], t2, time)
+                    st.inject(self.regions[k], t2, time, boundary=True)
             st.boundary_done()
             self.comm.exchange(self, t2)
-            st.stencil(GHOST, nx - GHOST - 1, t0, t1, t2, boundary=False)
-            if self.active["interior"]:
-                st.inject(self.regions["interior"], t2, time)
         else:
-            st.stencil(0, nx - 1, t0, t1, t2, boundary=False)
+            st.stencil(0, nx - 1, t0, t1, t2, boundary=True)
             if self.active["all"]:
-                st.inject(self.regions["all"], t2, time)
+                st.inject(self.regions["all"], t2, time, boundary=True)
             st.boundary_done()
             self.comm.exchange(self, t2)
 
@@ -169,10 +174,13 @@ class SlabPropagator:
         return self.stepper.mean_interior_kernel_ms()
 
     @classmethod
-    def standard_benchmark(cls, n_per_rank, ny, nz, nt, rank, world, device, variant=-1, global_x=0):
+    def standard_benchmark(cls, n_per_rank, ny, nz, nt, rank, world, device, variant=-1, global_x=0,
+                           self_exchange=False):
         """Weak-scaling benchmark state: global (n_per_rank*world) x ny x nz grid, u = 0, m = 1.5,
         h = 0.1, dt = 1e-3, one Ricker source at a quarter of the global extents
-        (main.cpp:285-356 applied to the global grid), built directly on the device."""
+        (main.cpp:285-356 applied to the global grid), built directly on the device.
+        `self_exchange` (world 1 only): the rank is its own left and right neighbour, so one GPU
+        runs the whole multi-GPU schedule including the RCCL messages."""
         import torch
         import torch.distributed as dist
         NX = global_x if global_x else n_per_rank * world   # strong scaling: fixed global extent
@@ -184,14 +192,39 @@ class SlabPropagator:
         src = torch.from_numpy(abi.fill_ricker(nt, 1)).to(device)
         coords = torch.from_numpy(abi.fill_source_coords(1, NX, ny, nz)).to(device)
         stepper = HipStepper(device, variant=variant, time_interior=True)
-        comm = TorchComm(dist, rank, world, stepper)
+        if self_exchange:
+            comm = TorchComm(dist, rank, world, stepper, left=rank, right=rank)
+        else:
+            comm = TorchComm(dist, rank, world, stepper)
         return cls(layout, rank, u, m, src, coords, dt=1e-3, h=(0.1, 0.1, 0.1), o=(0.0, 0.0, 0.0),
                    stepper=stepper, comm=comm)
 
 
+def init_rccl(device, rank=None, world=None):
+    """Process group for the ghost messages: backend "nccl" (= RCCL), communicator created eagerly
+    on `device`.  RCCL's stream keeps the default priority: with a high-priority stream the
+    first exchange was seen to never complete on an MI355X (device-side wait that no kernel
+    resolves), and the messages are hidden behind the interior sweep either way."""
+    import torch.distributed as dist
+    kw = {} if rank is None else {"rank": rank, "world_size": world}
+    dist.init_process_group("nccl", device_id=device, **kw)
+    return dist
+
+
 class HipStepper:
-    """Kernels from libfdtd_hip.so on two HIP streams: `compute` for the stencil and the scatter,
-    `comm` for the ghost messages."""
+    """Kernels from libfdtd_hip.so on two HIP streams.
+
+    `edge` carries the boundary chain of a step (outermost planes, their sources, then the ghost
+    messages, which the communication library runs on its own stream behind that point);
+    `inner` carries the interior chain.  Per step t:
+        edge : wait interior(t-1), wait messages(t-1); boundary update; scatter; record boundary(t)
+        inner: wait boundary(t-1);                     interior update; scatter; record interior(t)
+    Every wait names an event recorded earlier in host order, and these waits cover the
+    write-after-read hazards of the 3-level ring as well (a level is rewritten three steps after
+    it was written; its readers of steps t-1 and t-2 precede the awaited events on their streams).
+    A slab too thin to split (or a single rank) runs everything on `inner`."""
+
+    TIMING_STRIDE = 4   # every 4th interior launch is bracketed by timing events
 
     def __init__(self, device, variant=-1, time_interior=False):
         import torch
@@ -199,13 +232,14 @@ class HipStepper:
         self.lib = abi.lib()
         self.device = device
         self.variant = variant
-        self.compute = torch.cuda.current_stream(device)
-        self.comm_stream = torch.cuda.Stream(device)
-        self.ev_boundary = torch.cuda.Event()
-        self.ev_ghosts = torch.cuda.Event()
-        self.have_ghost_event = False
+        self.inner = torch.cuda.current_stream(device)
+        self.edge = self.inner
+        self.ev_boundary = None     # last recorded boundary / interior events
+        self.ev_interior = None
+        self.pending = []           # message requests the next boundary update waits for
         self.time_interior = time_interior
         self.timing = []
+        self._launches = 0
         self._geoms = {}
 
     def bind(self, prop):
@@ -216,12 +250,24 @@ class HipStepper:
         self.u_ptr, self.m_ptr = prop.u.data_ptr(), prop.m.data_ptr()
         self.src_ptr = prop.src.data_ptr() if prop.nsrc else None
         self.coords_ptr = prop.coords.data_ptr() if prop.nsrc else None
-        self.sh = C.c_void_p(self.compute.cuda_stream)
+        if prop.overlap:
+            self.edge = self.torch.cuda.Stream(self.device)
+            self.edge.wait_stream(self.inner)       # the fields were produced on the current stream
+        self.split = prop.overlap
+        self._sh = {True: C.c_void_p(self.edge.cuda_stream), False: C.c_void_p(self.inner.cuda_stream)}
 
     def begin_step(self):
+        if self.split:
+            if self.ev_interior is not None:
+                self.edge.wait_event(self.ev_interior)
+            if self.ev_boundary is not None:
+                self.inner.wait_event(self.ev_boundary)
         # the boundary update reads the ghosts delivered by the previous step's messages
-        if self.have_ghost_event:
-            self.compute.wait_event(self.ev_ghosts)
+        if self.pending:
+            with self.torch.cuda.stream(self.edge):
+                for req in self.pending:
+                    req.wait()          # stream-side wait; the host does not block
+            self.pending = []
 
     def stencil(self, x_lo, x_hi, t0, t1, t2, boundary):
         if x_hi < x_lo:
@@ -231,30 +277,41 @@ class HipStepper:
             g = abi.Geom.from_buffer_copy(self.geom)
             g.x_m, g.x_M = x_lo, x_hi
             self._geoms[(x_lo, x_hi)] = g
-        timed = self.time_interior and not boundary
+        stream = self.edge if boundary else self.inner
+        timed = self.time_interior and (not boundary or not self.split)
+        if timed:
+            self._launches += 1
+            timed = self._launches % self.TIMING_STRIDE == 0
         if timed:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
-            e0.record(self.compute)
-        rc = self.lib.fdtd_hip_stencil_step(C.byref(g), self.m_ptr, self.u_ptr, t0, t1, t2, self.variant, self.sh)
+            e0.record(stream)
+        rc = self.lib.fdtd_hip_stencil_step(C.byref(g), self.m_ptr, self.u_ptr, t0, t1, t2, self.variant,
+                                            self._sh[boundary])
         if rc:
             raise RuntimeError(f"fdtd_hip_stencil_step failed with hipError {rc}")
         if timed:
-            e1.record(self.compute)
+            e1.record(stream)
             self.timing.append((e0, e1))
 
-    def inject(self, region, t2, time):
+    def inject(self, region, t2, time, boundary):
         p = self.p
         rc = self.lib.fdtd_hip_source_inject_slab(
             C.byref(self.geom), self.m_ptr, self.src_ptr, self.coords_ptr, self.u_ptr, t2, time,
-            0, p.nsrc - 1, p.src.shape[1], p.coords.shape[1], p.x_off, region[0], region[1], self.sh)
+            0, p.nsrc - 1, p.src.shape[1], p.coords.shape[1], p.x_off, region[0], region[1], self._sh[boundary])
         if rc:
             raise RuntimeError(f"fdtd_hip_source_inject_slab failed with hipError {rc}")
 
     def boundary_done(self):
-        self.ev_boundary.record(self.compute)
+        if self.split:
+            self.ev_boundary = self.torch.cuda.Event()
+            self.ev_boundary.record(self.edge)
+
+    def interior_done(self):
+        self.ev_interior = self.torch.cuda.Event()
+        self.ev_interior.record(self.inner)
 
     def finish(self):
-        self.compute.wait_event(self.ev_ghosts) if self.have_ghost_event else None
+        self.begin_step()
         self.torch.cuda.synchronize(self.device)
 
     def mean_interior_kernel_ms(self):
@@ -269,19 +326,30 @@ class HipStepper:
 class TorchComm:
     """Ghost exchange with torch.distributed point-to-point messages (RCCL on GPUs).
 
-    With the "nccl" backend the messages are enqueued on the stepper's second stream behind the
-    boundary event, so they overlap the interior update.  With "gloo" (CPU tests, or several ranks
+    With the "nccl" backend the batch is issued from the stepper's boundary stream right after
+    the boundary work: RCCL's stream waits for that point and no further, so the messages run
+    next to the interior update, and the requests are handed to the stepper, whose next boundary
+    update waits for them on the device.  With "gloo" (CPU tests, or several ranks
     sharing one GPU) device tensors are staged through the host."""
 
-    def __init__(self, dist, rank, world, stepper=None):
+    _DEFAULT = object()
+
+    def __init__(self, dist, rank, world, stepper=None, left=_DEFAULT, right=_DEFAULT):
+        """`left` / `right`: peer ranks of the two ghost blocks (None = physical boundary).  The
+        default is the chain r-1 / r+1; a rank may name itself (RCCL matches a send to self with
+        the receive from self of the same batch, in order), which lets one process on one GPU
+        drive the full RCCL schedule."""
         self.dist, self.rank, self.world, self.stepper = dist, rank, world, stepper
-        self.backend = dist.get_backend() if world > 1 else None
+        self.left = (rank - 1 if rank > 0 else None) if left is self._DEFAULT else left
+        self.right = (rank + 1 if rank < world - 1 else None) if right is self._DEFAULT else right
+        self.has_neighbours = self.left is not None or self.right is not None
+        self.backend = dist.get_backend() if self.has_neighbours else None
         self._ops = {}
 
     def exchange(self, prop, lvl):
-        if self.world == 1:
+        if not self.has_neighbours:
             return
-        dist, r = self.dist, self.rank
+        dist = self.dist
         st = self.stepper
         on_gpu = prop.u.is_cuda
         if on_gpu and self.backend == "nccl":
@@ -289,34 +357,30 @@ class TorchComm:
             ops = self._ops.get(lvl)
             if ops is None:
                 ops = []
-                if r > 0:
-                    ops.append(dist.P2POp(dist.isend, prop.send_left(lvl), r - 1))
-                    ops.append(dist.P2POp(dist.irecv, prop.recv_left(lvl), r - 1))
-                if r < self.world - 1:
-                    ops.append(dist.P2POp(dist.isend, prop.send_right(lvl), r + 1))
-                    ops.append(dist.P2POp(dist.irecv, prop.recv_right(lvl), r + 1))
+                if self.left is not None:
+                    ops.append(dist.P2POp(dist.isend, prop.send_left(lvl), self.left))
+                    ops.append(dist.P2POp(dist.irecv, prop.recv_left(lvl), self.left))
+                if self.right is not None:
+                    ops.append(dist.P2POp(dist.isend, prop.send_right(lvl), self.right))
+                    ops.append(dist.P2POp(dist.irecv, prop.recv_right(lvl), self.right))
                 self._ops[lvl] = ops
-            with torch.cuda.stream(st.comm_stream):
-                st.comm_stream.wait_event(st.ev_boundary)
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-                st.ev_ghosts.record(st.comm_stream)
-                st.have_ghost_event = True
+            with torch.cuda.stream(st.edge):
+                st.pending = list(dist.batch_isend_irecv(ops))
             return
         # host-staged path
         if on_gpu:
             st.torch.cuda.synchronize(st.device)
         stage = (lambda t: t.cpu().contiguous()) if on_gpu else (lambda t: t.contiguous())
         reqs, recvs = [], []
-        if r > 0:
-            reqs.append(dist.isend(stage(prop.send_left(lvl)), r - 1))
+        if self.left is not None:
+            reqs.append(dist.isend(stage(prop.send_left(lvl)), self.left))
             buf = stage(prop.recv_left(lvl))
-            reqs.append(dist.irecv(buf, r - 1))
+            reqs.append(dist.irecv(buf, self.left))
             recvs.append((prop.recv_left(lvl), buf))
-        if r < self.world - 1:
-            reqs.append(dist.isend(stage(prop.send_right(lvl)), r + 1))
+        if self.right is not None:
+            reqs.append(dist.isend(stage(prop.send_right(lvl)), self.right))
             buf = stage(prop.recv_right(lvl))
-            reqs.append(dist.irecv(buf, r + 1))
+            reqs.append(dist.irecv(buf, self.right))
             recvs.append((prop.recv_right(lvl), buf))
         for q in reqs:
             q.wait()

@@ -23,6 +23,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The slab schedule keeps three device queues busy at once (interior chain, boundary chain, RCCL).
+# With HIP's default of 4 hardware queues per process the boundary stream was seen to land on the
+# interior stream's queue, which serialises the two chains; 8 keeps them apart.  Must be in the
+# environment before the HIP runtime initialises, i.e. before torch is imported.
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("FDTD_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 ALGO_BYTES_PER_CELL = 16.0     # read u[t0], u[t1], m; write u[t2]; 4 B each
 ALGO_BYTES_PER_CELL_F16 = 10.0  # fp16 storage: u levels 2 B each, m stays 4 B
@@ -39,6 +45,9 @@ def parse_args():
                     help="f16: wavefield levels stored as binary16 in HBM, fp32 arithmetic (config 4; N=1 only)")
     ap.add_argument("--global-x", type=int, default=0,
                     help="N>1: total planes along x split over the ranks (strong scaling), instead of --grid planes per rank")
+    ap.add_argument("--self-exchange", action="store_true",
+                    help="N=1 rehearsal of the N>1 schedule: the rank is its own two neighbours, RCCL messages "
+                         "included (measures what the exchange costs next to the interior sweep; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="oracle steps for the CPU baseline sample")
     return ap.parse_args()
@@ -90,19 +99,26 @@ def main():
     total_steps = K + W
     variant = pkg.VARIANTS[args.variant]
 
-    if world > 1:
+    slabs = world > 1 or args.self_exchange
+    if slabs:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # "nccl" is RCCL on ROCm.  FDTD_BENCH_BACKEND=gloo stages the ghosts through the host
         # (for rehearsing this path with several ranks on one GPU; never a performance number).
         backend = os.environ.get("FDTD_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            pkg.slab.init_rccl(dev)
         else:
             dist.init_process_group(backend)
         slab = pkg.slab
         prop = slab.SlabPropagator.standard_benchmark(n_per_rank=n, ny=n, nz=n, nt=total_steps,
                                                      rank=rank, world=world, device=dev,
-                                                     variant=variant, global_x=args.global_x)
+                                                     variant=variant, global_x=args.global_x,
+                                                     self_exchange=args.self_exchange and world == 1)
         for t in range(W):
             prop.step(t)
         torch.cuda.synchronize()
@@ -111,10 +127,15 @@ def main():
         t_start = time.perf_counter()
         for t in range(W, total_steps):
             prop.step(t)
-        torch.cuda.synchronize()
+        t_issue = time.perf_counter() - t_start
+        prop.stepper.finish()       # the last step's ghosts have arrived
+        t_fin = time.perf_counter() - t_start
         dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start
+        if os.environ.get("FDTD_BENCH_DEBUG"):
+            print(f"[rank {rank}] issue {t_issue*1e3:.3f} ms, finished {t_fin*1e3:.3f} ms, "
+                  f"after barrier {elapsed*1e3:.3f} ms", file=sys.stderr)
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -171,12 +192,12 @@ def main():
         return
 
     mcells = cells_per_step * K / elapsed / 1e6
-    if world == 1 and args.storage == "f16":
+    if not slabs and args.storage == "f16":
         globals()["ALGO_BYTES_PER_CELL"] = ALGO_BYTES_PER_CELL_F16
     achieved = ALGO_BYTES_PER_CELL * launch_cells / (kernel_ms * 1e-3) / 1e9  # GB/s, dominant kernel
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and world == 1 and n == 512 and args.storage == "f32" and args.variant == "auto":
+    if os.path.exists(tpath) and not slabs and n == 512 and args.storage == "f32" and args.variant == "auto":
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
@@ -197,7 +218,7 @@ def main():
         "achieved_hbm_GBps_whole_step": round(mcells * ALGO_BYTES_PER_CELL / 1e3, 1),
         "config": {
             "workload": (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
-                         f"{total_steps} steps ({W} untimed)" if world == 1 else
+                         f"{total_steps} steps ({W} untimed)" if not slabs else
                          f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, 2-plane ghost exchange "
                          f"per step over RCCL, {total_steps} steps ({W} untimed)"),
             "variant": args.variant,
@@ -214,7 +235,9 @@ def main():
             "avg_kernel_ms": round(kernel_ms, 4),
         },
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if slabs and world == 1:
+        out["config"]["workload"] += " [one rank, own neighbour on both sides: schedule rehearsal]"
+    if world == 1 and not slabs and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, n, args.cpu_steps)
     print(json.dumps(out))
 

@@ -45,7 +45,7 @@ class OracleStepper:
         self.ob.oracle_stencil_step(self.m, self.u, (x_lo, x_hi, 0, nyp - 9, 0, nzp - 9),
                                     np.float32(self.p.dt), tuple(np.float32(v) for v in self.p.h), t0, t1, t2)
 
-    def inject(self, region, t2, time):
+    def inject(self, region, t2, time, boundary):
         p = self.p
         nxp, nyp, nzp = self.u.shape[1:]
         self.ob.oracle().oracle_source_inject_slab(
@@ -56,12 +56,67 @@ class OracleStepper:
     def boundary_done(self):
         pass
 
+    def interior_done(self):
+        pass
+
     def finish(self):
         pass
 
 
+class SelfCopyComm:
+    """What a rank that is its own left and right neighbour receives: its own boundary planes."""
+    has_neighbours = True
+
+    def exchange(self, prop, lvl):
+        prop.recv_left(lvl).copy_(prop.send_left(lvl).clone())
+        prop.recv_right(lvl).copy_(prop.send_right(lvl).clone())
+
+
+def self_neighbour_run(name, outdir):
+    """One process, one GPU, backend "nccl": the rank names itself as both neighbours, so every
+    step runs the real RCCL messages on the second stream behind the boundary event.  Checked
+    bit for bit against the same orchestration on the CPU (oracle sweeps, plain copies)."""
+    pkg = load_package()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    pkg.slab.init_rccl(dev, 0, 1)
+    c = cases.build(name, pkg)
+    kw = c["kw"]
+    h, dt = kw.get("h", (0.1, 0.1, 0.1)), kw.get("dt", 1e-3)
+    NX = c["u"].shape[1] - 2 * HALO
+    time_m = kw.get("time_m", 0)
+    time_M = kw.get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
+    layout = pkg.slab.SlabLayout(NX, 1)
+    results = []
+    for kind in ("oracle", "hip"):
+        d = "cpu" if kind == "oracle" else dev
+        u_t, m_t = torch.from_numpy(c["u"].copy()).to(d), torch.from_numpy(c["m"]).to(d)
+        src_t = None if c["src"] is None else torch.from_numpy(c["src"]).to(d)
+        coords_t = None if c["coords"] is None else torch.from_numpy(c["coords"]).to(d)
+        if kind == "oracle":
+            stepper, comm = OracleStepper(), SelfCopyComm()
+        else:
+            stepper = pkg.slab.HipStepper(dev, variant=pkg.VARIANTS["auto"])
+            comm = pkg.slab.TorchComm(dist, 0, 1, stepper, left=0, right=0)
+            assert comm.backend == "nccl"
+        prop = pkg.slab.SlabPropagator(layout, 0, u_t, m_t, src_t, coords_t, dt=dt, h=h, o=(0.0, 0.0, 0.0),
+                                       stepper=stepper, comm=comm)
+        assert prop.overlap
+        prop.run(time_m, time_M)
+        results.append(u_t.cpu().numpy())
+    dist.destroy_process_group()
+    a, b = (r.view(np.uint32) for r in results)
+    nbad = int((a != b).sum())
+    ghosts_used = not np.array_equal(results[0][:, 2:4], c["u"][:, 2:4])
+    print(f"self-neighbour nccl run: {nbad} differing words, ghosts changed: {ghosts_used}")
+    np.save(os.path.join(outdir, "u_rank0.npy"), results[1])
+    sys.exit(0 if nbad == 0 and ghosts_used else 1)
+
+
 def main():
     kind, name, outdir = sys.argv[1:4]
+    if kind == "nccl_self":
+        return self_neighbour_run(name, outdir)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = load_package()

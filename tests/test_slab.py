@@ -73,3 +73,17 @@ def test_slab_orchestration_cpu(pkg, tmp_path, name, world):
 def test_slab_hip_two_ranks_one_gpu(pkg, tmp_path, name, world):
     u = run_slabs("hip", name, world, tmp_path, pkg)
     check_against_golden(name, u, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,march", [("ricker27_n32", False), ("ricker27_n32", True), ("time_offset", True)])
+def test_slab_rccl_schedule_one_gpu(pkg, tmp_path, name, march):
+    """The RCCL path itself (batched isend/irecv on the second stream, boundary and ghost events)
+    with one rank acting as its own two neighbours; bit-identical to the CPU orchestration."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if march:   # the marching kernel also on these small grids
+        env.update(FDTD_MARCH_MIN_CELLS="0", FDTD_MARCH_MIN_PLANES="1")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "slab_worker.py"), "nccl_self", name, str(tmp_path)],
+                       env=env, timeout=300)
+    assert p.returncode == 0
