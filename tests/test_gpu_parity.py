@@ -138,6 +138,25 @@ def test_size_independent_properties(pkg, hiplib):
 
 
 @pytest.mark.parametrize("op", OPERATORS)
+def test_impulse_mirror_symmetry(pkg, hiplib, op):
+    """Single-source symmetry check (suggested, not implemented, in DEBUG.md:500-512): a source
+    half-way between the two central nodes of every axis feeds 8 equal corners, and the update
+    (openacc.cpp:159-164) only ever adds the two members of a mirror pair to each other, so the
+    field stays bit-for-bit mirror symmetric about the centre in x, y and z.  192^3 takes the
+    marching kernel in Kernel_CUDA_Optimized."""
+    n, nt = 192, 24
+    h = 0.125                                       # power of two: (c - o)/h is exact
+    u, m, src, _ = pkg.standard_inputs(n, n, n, nt, 1)
+    coords = np.full((1, 3), (n / 2 - 0.5) * h, dtype=np.float32)
+    rc, _ = pkg.run_operator(getattr(hiplib, op), m, src, coords, u, h=(h, h, h))
+    assert rc == 0
+    f = u[:, 4:-4, 4:-4, 4:-4]
+    assert np.abs(f).max() > 0
+    for axis in (1, 2, 3):
+        assert np.array_equal(f, np.flip(f, axis=axis)), f"not mirror symmetric along axis {axis}"
+
+
+@pytest.mark.parametrize("op", OPERATORS)
 def test_atomic_scatter_path(pkg, hiplib, op, monkeypatch):
     """The atomic scatter: forced on the fixture cases (exact where no two corners share a cell,
     L2 < 1e-6 where they do), and taken by itself for 300 random sources."""
