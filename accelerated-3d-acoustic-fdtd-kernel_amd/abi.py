@@ -10,7 +10,7 @@ import numpy as np
 
 HALO = 4            # main.cpp:32, cuda.cu:55
 WARMUP_STEPS = 5    # openacc.cpp:5
-VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "auto": -1}
+VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "march2": 5, "auto": -1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -94,6 +94,12 @@ def lib():
     L.fdtd_hip_source_inject_slab.argtypes = L.fdtd_hip_source_inject.argtypes[:-1] + [
         C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.fdtd_hip_source_inject_slab.restype = C.c_int
+    L.fdtd_hip_two_steps.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]
+    L.fdtd_hip_two_steps.restype = C.c_int
+    L.fdtd_hip_one_step.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]
+    L.fdtd_hip_one_step.restype = C.c_int
+    L.fdtd_hip_copy_shell.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.fdtd_hip_copy_shell.restype = C.c_int
     L.fdtd_hip_time_loop.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.POINTER(Profiler)]

@@ -35,6 +35,7 @@ struct InjectArgs {
   // is applied iff its GLOBAL x index lies in [x_lo, x_hi].  Single-domain calls use
   // x_shift = 0, x_lo = x_m - 1, x_hi = x_M + 1 (openacc.cpp:192).
   int x_shift, x_lo, x_hi;
+  int target_mode;  // 0: all admitted corners; 1: only those landing outside [x_m..x_M]x[y_m..y_M]x[z_m..z_M]
 };
 
 #define FDTD_HIP_CHECK(expr)                  \
@@ -42,3 +43,21 @@ struct InjectArgs {
     hipError_t _e = (expr);                   \
     if (_e != hipSuccess) return (int)_e;     \
   } while (0)
+
+// Launchers on explicit level pointers (defined in fdtd_kernels.hip), used by the time loops that
+// rotate more than three level buffers.
+int fdtd_stencil_levels(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
+                        float *u2, int variant, void *stream);
+int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *src,
+                      const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
+                      int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
+                      void *stream);
+
+// fdtd_march2.hip: can the two-steps-per-sweep kernel take this problem?
+bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float *b, const float *a_prev,
+                          const float *c, const float *d, int nsrc);
+int fdtd_shells_differ(const struct fdtd_geom *g, const float *a, const float *b, int *flag, void *stream);
+int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
+                        const float *src_coords, const float *cur, const float *prev, float *next1,
+                        float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                        int variant, void *stream, hipEvent_t mid);

@@ -592,6 +592,14 @@ __global__ __launch_bounds__(512) void stencil_tile3d_kernel(StencilArgs a, int 
 // device-scope float atomic (cuda.cu:165).  Corners of one source never coincide, so with
 // sources that do not share cells the result does not depend on the order the atomics land in.
 // ---------------------------------------------------------------------------------
+// target_mode 1 keeps only the corners that land outside the updated box, i.e. in the first halo
+// layer (openacc.cpp:192 admits one cell beyond every face).
+__device__ __forceinline__ bool inject_target_selected(const InjectArgs &a, int x, int y, int z) {
+  if (a.target_mode == 0) return true;
+  const bool inside = x >= a.x_m && x <= a.x_M && y >= a.y_m && y <= a.y_M && z >= a.z_m && z <= a.z_M;
+  return !inside;
+}
+
 __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int nsrc = a.p_src_M - a.p_src_m + 1;
@@ -606,7 +614,8 @@ __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
   const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
 
   if (rx + posx >= a.x_lo && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
-      rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
+      rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1 &&
+      inject_target_selected(a, rx + posx, ry + posy, rz + posz)) {
     const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
                      (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
                      a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
@@ -639,7 +648,8 @@ __global__ __launch_bounds__(1024) void source_inject_ordered_kernel(InjectArgs 
     const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
     const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
     if (rx + posx >= a.x_lo && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 &&
-        rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1) {
+        rx + posx <= a.x_hi && ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1 &&
+        inject_target_selected(a, rx + posx, ry + posy, rz + posz)) {
       r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
            (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
            a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
@@ -683,13 +693,12 @@ static bool march_eligible(const fdtd_geom *g, const float *m, const float *u) {
          (((uintptr_t)m | (uintptr_t)u) % 16 == 0) && (((long)g->nxp * g->nyp * g->nzp) % 4 == 0);
 }
 
-static StencilArgs make_args(const fdtd_geom *g, const float *m, float *u, int t0, int t1, int t2) {
+static StencilArgs make_args(const fdtd_geom *g, const float *m, const float *u0, const float *u1, float *u2) {
   StencilArgs a;
-  const long vol = (long)g->nxp * g->nyp * g->nzp;
   a.m = m;
-  a.u0 = u + (long)t0 * vol;
-  a.u1 = u + (long)t1 * vol;
-  a.u2 = u + (long)t2 * vol;
+  a.u0 = u0;
+  a.u1 = u1;
+  a.u2 = u2;
   a.sx = (long)g->nyp * g->nzp;
   a.sy = g->nzp;
   a.nxp = g->nxp; a.nyp = g->nyp; a.nzp = g->nzp;
@@ -820,14 +829,16 @@ static int launch_march_any(const StencilArgs &a, const void *u0, const void *u1
   return (int)hipErrorInvalidValue;
 }
 
-extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, float *u, int t0,
-                                     int t1, int t2, int variant, void *stream) {
-  if (!geom_valid(g) || !m || !u) return (int)hipErrorInvalidValue;
-  if (t0 < 0 || t0 > 2 || t1 < 0 || t1 > 2 || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
+// One sweep on explicit level pointers (the levels need not be the three slots of one array).
+int fdtd_stencil_levels(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
+                        float *u2, int variant, void *stream) {
+  if (!geom_valid(g) || !m || !u0 || !u1 || !u2) return (int)hipErrorInvalidValue;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   if (ex <= 0 || ey <= 0 || ez <= 0) return 0;  // empty range: nothing to update
   hipStream_t s = (hipStream_t)stream;
-  const StencilArgs a = make_args(g, m, u, t0, t1, t2);
+  const StencilArgs a = make_args(g, m, u0, u1, u2);
+  const bool eligible = march_eligible(g, m, u0) && march_eligible(g, u1, u2);
+  if (variant == FDTD_VARIANT_MARCH2) variant = FDTD_VARIANT_AUTO;   // a single sweep cannot fuse
 
   if (variant == FDTD_VARIANT_AUTO) {
     // Measured crossover on MI355X: below ~160^3 cells a sweep is a handful of microseconds
@@ -836,12 +847,11 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
     const long cells = (long)ex * ey * ez;
     // Ranges of fewer than 8 planes (the boundary planes of a slab) would spend more on priming
     // the register column than on the sweep: naive kernel as well.
-    variant = (march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000) &&
+    variant = (eligible && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000) &&
                ex >= env_int("FDTD_MARCH_MIN_PLANES", 8))
                   ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
   }
-  if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) &&
-      !march_eligible(g, m, u))
+  if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) && !eligible)
     variant = FDTD_VARIANT_NAIVE;
 
   switch (variant) {
@@ -890,18 +900,28 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
   return (int)hipGetLastError();
 }
 
-static int launch_inject(const struct fdtd_geom *g, const float *m, const float *src,
-                         const float *src_coords, float *u, int t2, int time, int p_src_m, int p_src_M,
-                         int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, void *stream) {
+extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, float *u, int t0,
+                                     int t1, int t2, int variant, void *stream) {
+  if (!g || !u) return (int)hipErrorInvalidValue;
+  if (t0 < 0 || t0 > 2 || t1 < 0 || t1 > 2 || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
+  const long vol = (long)g->nxp * g->nyp * g->nzp;
+  return fdtd_stencil_levels(g, m, u + (long)t0 * vol, u + (long)t1 * vol, u + (long)t2 * vol, variant, stream);
+}
+
+// The scatter on an explicit level pointer.  target_mode 0: every corner inside the reference's
+// bounds; 1: only corners whose target cell lies outside the updated box (the first halo layer).
+int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *src,
+                      const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
+                      int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
+                      void *stream) {
   if (p_src_M < p_src_m) return 0;
-  if (!g || !m || !src || !src_coords || !u || t2 < 0 || t2 > 2 || coord_stride < 3 ||
-      src_stride < 1)
+  if (!g || !m || !src || !src_coords || !level || coord_stride < 3 || src_stride < 1)
     return (int)hipErrorInvalidValue;
   if (x_hi < x_lo) return 0;
   InjectArgs a;
-  const long vol = (long)g->nxp * g->nyp * g->nzp;
   a.m = m; a.src = src; a.coords = src_coords;
-  a.u2 = u + (long)t2 * vol;
+  a.u2 = level;
+  a.target_mode = target_mode;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
@@ -915,6 +935,16 @@ static int launch_inject(const struct fdtd_geom *g, const float *m, const float 
     hipLaunchKernelGGL(source_inject_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+static int launch_inject(const struct fdtd_geom *g, const float *m, const float *src,
+                         const float *src_coords, float *u, int t2, int time, int p_src_m, int p_src_M,
+                         int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, void *stream) {
+  if (p_src_M < p_src_m) return 0;
+  if (!g || !u || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
+  const long vol = (long)g->nxp * g->nyp * g->nzp;
+  return fdtd_inject_level(g, m, src, src_coords, u + (long)t2 * vol, time, p_src_m, p_src_M, src_stride,
+                           coord_stride, x_shift, x_lo, x_hi, 0, stream);
 }
 
 extern "C" int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m, const float *src,
@@ -1027,7 +1057,7 @@ extern "C" int fdtd_hip_stencil_step_h16(const struct fdtd_geom *g, const float 
   if (ex <= 0 || ey <= 0 || ez <= 0) return 0;
   if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
   StencilArgsH16 h;
-  h.f = make_args(g, m, nullptr, 0, 0, 0);
+  h.f = make_args(g, m, nullptr, nullptr, nullptr);
   const long vol = (long)g->nxp * g->nyp * g->nzp;
   __half *u = (__half *)u_h16;
   h.m = m;
@@ -1068,6 +1098,7 @@ extern "C" int fdtd_hip_source_inject_h16(const struct fdtd_geom *g, const float
   a.p_src_m = p_src_m; a.p_src_M = p_src_M; a.time = time;
   a.src_stride = src_stride; a.coord_stride = coord_stride;
   a.x_shift = 0; a.x_lo = g->x_m - 1; a.x_hi = g->x_M + 1;
+  a.target_mode = 0;
   const long threads = (long)(p_src_M - p_src_m + 1) * 8;
   hipLaunchKernelGGL(source_inject_h16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, h);

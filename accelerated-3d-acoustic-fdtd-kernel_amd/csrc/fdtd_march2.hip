@@ -1,0 +1,584 @@
+// fdtd_march2.hip — two time steps per sweep (the reference's t_fuse knob, main.cpp:261,267, which
+// no reference kernel implements).
+//
+// One launch advances the field by two leapfrog steps of openacc.cpp:159-164 and applies the
+// source scatter of the first of them (openacc.cpp:185-196) in between, so the result is bit for
+// bit what two single sweeps with a scatter after each give.  It reads B = u(t), A = u(t-1) and
+// m, and writes C = u(t+1) and D = u(t+2): five level-sized streams for two updates of every
+// cell, 10 B per cell update instead of 16.  D is a fourth buffer: it cannot overwrite A in
+// place, because neighbouring workgroups still read A for the rows they compute redundantly.
+//
+// Tile: 8 output rows x 512 cells (the whole z extent) marching along x; 8 waves.  C is
+// computed on 12 rows (2 redundant rows per side) from B on 16 rows; D on the 8 rows, two planes
+// behind C.  Wave (q, h) owns z-half h of three row segments of 256 cells (one float4 per lane):
+//   segment 0: an inner output row (2..5 of the tile): nobody else loads it, its A and m stream
+//   segment 1: an outer output row (0, 1, 6, 7): the neighbouring tile recomputes C there
+//   segment 2: a redundant row (-2, -1, 8, 9): C only, an outer output row of the neighbour
+// x-neighbours: two 5-plane register rings (B for 3 segments, C for 2), advanced by renaming —
+// the steady-state loop is unrolled 5 times.  y-neighbours: LDS (B centre planes double
+// buffered, C planes in a ring of 3), one workgroup barrier per plane.  z-neighbours: DPP
+// wavefront shifts inside a wave, LDS between the two halves of a row, 8-byte edge loads at the
+// ends of the row.  Rows and planes of C outside the updated box are never computed: like a
+// single sweep, the second step reads what the C level holds there in memory.
+// Everything that comes from memory is reloaded for the next plane right after its last use,
+// into the same registers (one register set, a whole iteration between a load and its use, exact
+// counted waits).  Memory is addressed with buffer instructions: descriptor (scalar) + plane
+// offset (scalar) + one loop-invariant 32-bit lane offset per row.
+//
+// Shapes: z extent exactly 512 cells, y extent a multiple of 8, at most 8 sources; anything else
+// is run as two single sweeps by fdtd_hip_two_steps.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "fdtd_device.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int M2_ROWS = 8;        // output rows per tile
+constexpr int M2_ZCELLS = 512;    // z extent
+constexpr int M2_MAX_SRC = 8;     // 8 corners each: one lane per corner
+
+struct Coef2 { float cm2, cm1, c0, dt2, r1, r2, r3, r4, neg2r1; };
+
+struct March2Args {
+  const char *B, *A, *m;
+  char *C, *D;
+  long sx;            // cells per plane
+  int sy;             // cells per row
+  int x_m, x_M;       // planes of this launch (cut into x-chunks)
+  int dx_m, dx_M;     // planes of the whole updated box: C outside of it is never computed
+  int y_m, y_M, z_m;
+  Coef2 k;
+  // source scatter of the first step (time index `time`), applied to C between the two updates
+  const float *src_row;   // src + time * src_stride
+  const float *coords;
+  const float *m_f;
+  int nsrc, p_src_m, coord_stride;
+  int z_M;
+  float h_x, h_y, h_z, o_x, o_y, o_z;
+};
+
+__device__ __forceinline__ float dpp_prev(float edge, float v) {  // lane i <- lane i-1; lane 0 keeps `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_next(float edge, float v) {  // lane i <- lane i+1; lane 63 keeps `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, j = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+// Buffer access: aux 2 = non-temporal.  gfx9 raw buffer descriptor word 3: DATA_FORMAT = 32 bit.
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ f32x4 ld4(rsrc_t r, int soff, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, NT ? 2 : 0));
+}
+__device__ __forceinline__ f32x2 ld2(rsrc_t r, int soff, unsigned voff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
+template <bool NT>
+__device__ __forceinline__ void st4(rsrc_t r, int soff, unsigned voff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, NT ? 2 : 0);
+}
+
+// One row segment, 4 cells per lane, evaluated on register pairs: a float4 lives in four
+// consecutive registers, so its (x,y) and (z,w) halves are aligned pairs and every x/y-direction
+// term maps onto packed fp32 instructions without shuffling; only the z-direction mixes the
+// members of a pair.  Per cell: the operations, order and rounding of openacc.cpp:159-164.
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return f32x2{v.x, v.y}; }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return f32x2{v.z, v.w}; }
+__device__ __forceinline__ f32x2 update_pair(const Coef2 &k, f32x2 uc, f32x2 xm2, f32x2 xm1, f32x2 xp1, f32x2 xp2,
+                                             f32x2 ym2, f32x2 ym1, f32x2 yp1, f32x2 yp2, f32x2 zs2, f32x2 zs1, f32x2 up,
+                                             f32x2 mc) {
+  // zs2 = u(z-2) + u(z+2), zs1 = u(z-1) + u(z+1)
+  const f32x2 r5 = k.c0 * uc;
+  const f32x2 dxx = r5 + k.cm2 * (xm2 + xp2) + k.cm1 * (xm1 + xp1);
+  const f32x2 dyy = r5 + k.cm2 * (ym2 + yp2) + k.cm1 * (ym1 + yp1);
+  const f32x2 dzz = r5 + k.cm2 * zs2 + k.cm1 * zs1;
+  const f32x2 num = k.dt2 * (k.r2 * dxx + k.r3 * dyy + k.r4 * dzz - (k.neg2r1 * uc + k.r1 * up) * mc);
+  return f32x2{num.x / mc.x, num.y / mc.y};
+}
+__device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, f32x4 xm1, f32x4 xp1, f32x4 xp2,
+                                            f32x4 ym2, f32x4 ym1, f32x4 yp1, f32x4 yp2, f32x2 eL, f32x2 eR, f32x4 up,
+                                            f32x4 mc) {
+  const f32x2 l = f32x2{dpp_prev(eL.x, c.z), dpp_prev(eL.y, c.w)};   // cells z-2, z-1 of cell 0
+  const f32x2 r = f32x2{dpp_next(eR.x, c.x), dpp_next(eR.y, c.y)};   // cells z+1, z+2 of cell 3
+  const f32x2 cl = lo2(c), ch = hi2(c);
+  // cells 0,1: z-2: (l.x, l.y)  z+2: (c.z, c.w)   z-1: (l.y, c.x)  z+1: (c.y, c.z)
+  // cells 2,3: z-2: (c.x, c.y)  z+2: (r.x, r.y)   z-1: (c.y, c.z)  z+1: (c.w, r.x)
+  const f32x2 zs2_lo = l + ch, zs2_hi = cl + r;
+  const f32x2 zs1_lo = f32x2{l.y + c.y, c.x + c.z}, zs1_hi = f32x2{c.y + c.w, c.z + r.x};
+  const f32x2 olo = update_pair(k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1), lo2(yp2),
+                                zs2_lo, zs1_lo, lo2(up), lo2(mc));
+  const f32x2 ohi = update_pair(k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1), hi2(yp2),
+                                zs2_hi, zs1_hi, hi2(up), hi2(mc));
+  return f32x4{olo.x, olo.y, ohi.x, ohi.y};
+}
+
+template <bool NT>
+__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt) {
+  __shared__ f32x4 Bbuf[2][16][128];
+  __shared__ f32x4 Cring[3][12][128];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = wave & 1, q = wave >> 1;
+  const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int yt = t % nyt, xc = t / nyt;
+  const int yb = a.y_m + yt * M2_ROWS;
+  const int x_begin = a.x_m + xc * xchunk;
+  const int x_end = min(x_begin + xchunk - 1, a.x_M);
+  const Coef2 k = a.k;
+
+  // rows of the three segments and their slots in the 12-row C stack (slot = row - yb + 2)
+  const int yrow[3] = {yb + 2 + q, q < 2 ? yb + q : yb + 4 + q, q < 2 ? yb - 2 + q : yb + 6 + q};
+  const int cslot[3] = {4 + q, q < 2 ? 2 + q : 6 + q, q < 2 ? q : 8 + q};
+  const bool seg2_outside = yrow[2] < a.y_m || yrow[2] > a.y_M;
+  const int yhalo = q < 2 ? yb - 4 + q : yb + 8 + q;   // B row outside the 12-row stack
+  const int hslot = q < 2 ? q : 12 + q;
+  const int lz = h * 64 + lane;                         // float4 index inside the 512-cell row
+  const unsigned zc = (unsigned)(a.z_m + lz * 4 + FDTD_HALO);
+  unsigned voff[3], veoff[3], vceoff[2];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    // byte offsets inside a plane
+    voff[s] = ((unsigned)(yrow[s] + FDTD_HALO) * (unsigned)a.sy + zc) * 4u;
+    veoff[s] = lane == 63 ? voff[s] + 16u : voff[s] - 8u;   // cells (z+4, z+5) or (z-2, z-1)
+  }
+  // C array edges: only the two cells before lane 0 / behind lane 63 are ever used; the lanes in
+  // between repeat lane 0's address instead of touching the whole row
+#pragma unroll
+  for (int s = 0; s < 2; ++s) vceoff[s] = lane == 63 ? voff[s] + 16u : voff[s] - (unsigned)lane * 16u - 8u;
+  const unsigned vhoff = ((unsigned)(yhalo + FDTD_HALO) * (unsigned)a.sy + zc) * 4u;
+  const int sxb = (int)(a.sx * 4);   // bytes per plane
+
+  // descriptors are based at the lowest plane this workgroup touches, so that plane offsets stay
+  // below 2^31 whatever the size of a level
+  const int p0 = x_begin - 2, p_last = x_end + 2;
+  const long base = (long)(p0 - 2 + FDTD_HALO) * a.sx * 4;
+  const rsrc_t rB = make_rsrc(a.B + base, 0xffffffffu), rA = make_rsrc(a.A + base, 0xffffffffu);
+  const rsrc_t rM = make_rsrc(a.m + base, 0xffffffffu);
+  const rsrc_t rC = make_rsrc(a.C + base, 0xffffffffu), rD = make_rsrc(a.D + base, 0xffffffffu);
+  int sp = 2 * sxb;   // byte offset of plane p
+
+  // ---- source corners of the first step: lane l holds corner l (source l / 8, corner l % 8) ----
+  bool cvalid = false;
+  int cx = 0, cy = 0, cz = 0;
+  float cval = 0.f;
+  if (lane < a.nsrc * 8) {
+    const int p = a.p_src_m + (lane >> 3);
+    const int rx = (lane >> 2) & 1, ry = (lane >> 1) & 1, rz = lane & 1;
+    const float gx = (-a.o_x + a.coords[(long)p * a.coord_stride + 0]) / a.h_x;
+    const float gy = (-a.o_y + a.coords[(long)p * a.coord_stride + 1]) / a.h_y;
+    const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
+    const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
+    const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
+    cx = rx + posx; cy = ry + posy; cz = rz + posz;
+    // corners that land in the first halo layer are applied to memory before the launch
+    cvalid = cx >= a.dx_m && cx <= a.dx_M && cy >= a.y_m && cy <= a.y_M && cz >= a.z_m && cz <= a.z_M;
+    if (cvalid)
+      cval = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
+             (rz * pz + (1 - rz) * (1 - pz)) * a.src_row[p] /
+             a.m_f[(long)(posx + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy + (posz + FDTD_HALO)];
+  }
+
+#define LD4(r, so, off) ld4<false>(r, so, off)
+#define LD4S(r, so, off) ld4<NT>(r, so, off)
+#define LD2(r, so, off) ld2(r, so, off)
+
+  f32x4 bc[5][3];     // B planes p-2 .. p+2 (logical plane i lives in bc[(J+i)%5] at phase J)
+  f32x4 cc[5][2];     // C planes p-4 .. p-1 and the new plane p (output rows)
+  f32x4 mh[2][2];     // m planes p-2, p-1 (output rows)
+  f32x4 av[3], mv[3]; // A, m of plane p
+  f32x2 be[3];        // z-edge cells of B, plane p
+  f32x4 bh, bh2;      // B row outside the stack, planes p+1 and p+2 (fetched when the neighbouring tile
+                      // fetches the same row as one of its own: plane p+3)
+  f32x2 ce[2];        // z-edge cells of the C array (halo of the domain), plane p-2
+  f32x4 ch;           // C row of the redundant segment when that row is outside the domain, plane p
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, sp + (i - 2) * sxb, voff[s]);
+    av[s] = s == 0 ? LD4S(rA, sp, voff[s]) : LD4(rA, sp, voff[s]);
+    mv[s] = s == 0 ? LD4S(rM, sp, voff[s]) : LD4(rM, sp, voff[s]);
+    be[s] = LD2(rB, sp, veoff[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) cc[i][s] = f32x4{0, 0, 0, 0};
+    mh[0][s] = mh[1][s] = f32x4{1, 1, 1, 1};
+    ce[s] = f32x2{0, 0};
+  }
+  bh = LD4(rB, sp + sxb, vhoff);
+  bh2 = LD4(rB, sp + 2 * sxb, vhoff);
+  ch = seg2_outside ? LD4(rC, sp, voff[2]) : f32x4{0, 0, 0, 0};
+  {  // B(p0): own rows and the outside row
+    const int buf = p0 & 1;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) Bbuf[buf][cslot[s] + 2][lz] = bc[2][s];
+    Bbuf[buf][hslot][lz] = LD4(rB, sp, vhoff);
+  }
+  __syncthreads();
+  int ring_w = ((p0 % 3) + 3) % 3;        // ring slot written this iteration (plane p)
+  int ring_r = (((p0 - 2) % 3) + 3) % 3;  // ring slot of plane p-2
+
+  // One plane.  STEADY: plane inside the box and the chunk, second step active, no branch around
+  // a memory instruction, ring phase J.  Otherwise (J = 0): every condition checked, rings
+  // advanced by register moves.
+  auto iteration = [&](auto phase, auto steady, int p) __attribute__((always_inline)) {
+    constexpr int J = decltype(phase)::value;
+    constexpr bool STEADY = decltype(steady)::value;
+#define PB(i) bc[(J + (i)) % 5]
+#define PC(i) cc[(J + (i)) % 5]
+    const int buf = p & 1;
+    const bool more = STEADY ? true : p < p_last;
+    const int sq = sp + (more ? sxb : 0);   // plane p+1 (repeats plane p at the very end)
+    const bool plane_inside = STEADY ? true : (p >= a.dx_m && p <= a.dx_M);
+    const bool store_c = STEADY ? true : (plane_inside && p >= x_begin && p <= x_end);
+    const int d = p - 2;
+    const bool do_d = STEADY ? true : (d >= x_begin && d <= x_end);
+    const unsigned long cmask = __ballot(cvalid && cx == p);   // corners of the first step in this plane
+
+    auto compute = [&](auto seg) __attribute__((always_inline)) {
+      constexpr int s = decltype(seg)::value;
+      const int r = cslot[s];   // the row's slot in Bbuf is r + 2
+      // ---- C(p) ----
+      f32x4 cnew;
+      if (plane_inside) {
+        const f32x4 ym2 = Bbuf[buf][r][lz], ym1 = Bbuf[buf][r + 1][lz];
+        const f32x4 yp1 = Bbuf[buf][r + 3][lz], yp2 = Bbuf[buf][r + 4][lz];
+        cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
+                          mv[s]);
+        if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
+        if (cmask) {   // wave-uniform; source order = lane order = the reference's loop order
+          unsigned long mm = cmask;
+          while (mm) {
+            const int b = __builtin_ctzl(mm);
+            mm &= mm - 1;
+            const int sy_ = __builtin_amdgcn_readlane(cy, b), sz_ = __builtin_amdgcn_readlane(cz, b);
+            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cval), b));
+            const int zi = sz_ - a.z_m;
+            const bool hit = sy_ == yrow[s] && (zi >> 2) == lz;
+            const int comp = zi & 3;
+            const f32x4 added = cnew + f32x4{sv, sv, sv, sv};
+            cnew.x = (hit && comp == 0) ? added.x : cnew.x;
+            cnew.y = (hit && comp == 1) ? added.y : cnew.y;
+            cnew.z = (hit && comp == 2) ? added.z : cnew.z;
+            cnew.w = (hit && comp == 3) ? added.w : cnew.w;
+          }
+        }
+      } else {   // halo plane of the domain: the intermediate level keeps what memory holds there
+        cnew = LD4(rC, sp, voff[s]);
+      }
+      if constexpr (s < 2) {
+        if (store_c) st4<NT>(rC, sp, voff[s], cnew);
+      }
+      Cring[ring_w][r][lz] = cnew;
+      // ---- D(p-2) ----
+      if constexpr (s < 2) {
+        if (do_d) {
+          const f32x4 ym2 = Cring[ring_r][r - 2][lz], ym1 = Cring[ring_r][r - 1][lz];
+          const f32x4 yp1 = Cring[ring_r][r + 1][lz], yp2 = Cring[ring_r][r + 2][lz];
+          const f32x4 nb = Cring[ring_r][r][h ? 63 : 64];   // the other z-half of the same row
+          const f32x2 eL = h ? f32x2{nb.z, nb.w} : ce[s];
+          const f32x2 eR = h ? ce[s] : f32x2{nb.x, nb.y};
+          const f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
+                                     PB(0)[s], mh[0][s]);
+          st4<NT>(rD, sp - 2 * sxb, voff[s], o);
+        }
+        if (STEADY) {
+          PC(4)[s] = cnew;
+        } else {
+          cc[0][s] = cc[1][s];
+          cc[1][s] = cc[2][s];
+          cc[2][s] = cc[3][s];
+          cc[3][s] = cnew;
+        }
+        mh[0][s] = mh[1][s];
+        mh[1][s] = mv[s];
+      }
+    };
+    // advance the B ring of a segment and reload what plane p+1 needs
+    auto reload = [&](auto seg) __attribute__((always_inline)) {
+      constexpr int s = decltype(seg)::value;
+      const int r = cslot[s];
+      if constexpr (s < 2) ce[s] = LD2(rC, sq - 2 * sxb, vceoff[s]);   // C array, plane (p+1)-2
+      if (STEADY) {
+        Bbuf[buf ^ 1][r + 2][lz] = PB(3)[s];           // B(p+1), centre plane of the next iteration
+        PB(0)[s] = LD4(rB, sq + 2 * sxb, voff[s]);     // B(p+3) replaces B(p-2)
+      } else {
+        bc[0][s] = bc[1][s];
+        bc[1][s] = bc[2][s];
+        bc[2][s] = bc[3][s];
+        bc[3][s] = bc[4][s];
+        Bbuf[buf ^ 1][r + 2][lz] = bc[2][s];
+        bc[4][s] = LD4(rB, sq + 2 * sxb, voff[s]);
+      }
+      av[s] = s == 0 ? LD4S(rA, sq, voff[s]) : LD4(rA, sq, voff[s]);
+      mv[s] = s == 0 ? LD4S(rM, sq, voff[s]) : LD4(rM, sq, voff[s]);
+      be[s] = LD2(rB, sq, veoff[s]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // Outer and redundant rows first, and their reloads back to back: the neighbouring tile asks
+    // for the same rows (as its redundant / outer rows) at the same point of its iteration, so
+    // one of the two requests finds the line in L2.
+    compute(S1{});
+    compute(S2{});
+    reload(S1{});
+    reload(S2{});
+    compute(S0{});
+    reload(S0{});
+    Bbuf[buf ^ 1][hslot][lz] = bh;
+    bh = bh2;
+    bh2 = LD4(rB, sq + 2 * sxb, vhoff);
+    if (seg2_outside) ch = LD4(rC, sq, voff[2]);
+    __syncthreads();
+    ring_w = ring_w == 2 ? 0 : ring_w + 1;
+    ring_r = ring_r == 2 ? 0 : ring_r + 1;
+    sp += sxb;
+#undef PB
+#undef PC
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  int p = p0;
+  // lead-in: two planes before the chunk, two planes without the second step
+  for (; p < x_begin + 2 && p <= p_last; ++p) iteration(std::integral_constant<int, 0>{}, F{}, p);
+  // steady state in groups of five planes, all of them inside [x_begin + 2, x_end - 1]
+  for (; p + 4 <= x_end - 1; p += 5) {
+    iteration(std::integral_constant<int, 0>{}, T{}, p);
+    iteration(std::integral_constant<int, 1>{}, T{}, p + 1);
+    iteration(std::integral_constant<int, 2>{}, T{}, p + 2);
+    iteration(std::integral_constant<int, 3>{}, T{}, p + 3);
+    iteration(std::integral_constant<int, 4>{}, T{}, p + 4);
+  }
+  for (; p <= p_last; ++p) iteration(std::integral_constant<int, 0>{}, F{}, p);
+#undef LD4
+#undef LD4S
+#undef LD2
+}
+
+// The shell: the two layers of cells around the updated box, i.e. every halo cell a sweep can
+// read (openacc.cpp:161-163) or a scatter can touch (openacc.cpp:192).  One wave per (x, y) row
+// of the box grown by 2; rows outside the box in x or y are copied whole, rows inside it only
+// contribute their 2 + 2 cells beyond the z range.
+// mode 0: copy shell and box;  1: copy the shell only;  2: compare the shells of a and b bit for
+// bit and set *flag when they differ.
+struct ShellArgs {
+  float *dst;
+  const float *a, *b;
+  int *flag;
+  long sx, sy;
+  int x_m, x_M, y_m, y_M, z_m, z_M;
+  int mode;
+};
+__global__ __launch_bounds__(64) void shell_kernel(ShellArgs s) {
+  const int ny = s.y_M - s.y_m + 5;
+  const int x = s.x_m - 2 + (int)(blockIdx.x / ny), y = s.y_m - 2 + (int)(blockIdx.x % ny);
+  const bool row_in_shell = x < s.x_m || x > s.x_M || y < s.y_m || y > s.y_M;
+  const long row = (long)(x + FDTD_HALO) * s.sx + (long)(y + FDTD_HALO) * s.sy + FDTD_HALO;
+  const int ez = s.z_M - s.z_m + 1;
+  bool differ = false;
+  auto visit = [&](int z) {
+    const long c = row + z;
+    if (s.mode == 2) differ |= __float_as_uint(s.a[c]) != __float_as_uint(s.b[c]);
+    else s.dst[c] = s.a[c];
+  };
+  if (row_in_shell || s.mode == 0) {
+    for (int i = threadIdx.x; i < ez + 4; i += 64) visit(s.z_m - 2 + i);
+  } else if (threadIdx.x < 4) {
+    visit(threadIdx.x < 2 ? s.z_m - 2 + (int)threadIdx.x : s.z_M - 1 + (int)threadIdx.x);
+  }
+  if (s.mode == 2 && __any(differ) && threadIdx.x == 0) atomicOr(s.flag, 1);
+}
+
+int launch_shell(const struct fdtd_geom *g, float *dst, const float *a, const float *b, int *flag, int mode,
+                 hipStream_t st) {
+  ShellArgs s;
+  s.dst = dst; s.a = a; s.b = b; s.flag = flag;
+  s.sx = (long)g->nyp * g->nzp; s.sy = g->nzp;
+  s.x_m = g->x_m; s.x_M = g->x_M; s.y_m = g->y_m; s.y_M = g->y_M; s.z_m = g->z_m; s.z_M = g->z_M;
+  s.mode = mode;
+  const long rows = (long)(g->x_M - g->x_m + 5) * (g->y_M - g->y_m + 5);
+  if (rows <= 0 || rows > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(shell_kernel, dim3((unsigned)rows), dim3(64), 0, st, s);
+  return (int)hipGetLastError();
+}
+
+int env_int2(const char *name, int fallback) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : fallback;
+}
+
+}  // namespace
+
+// Can the fused kernel take this problem?  (Everything else goes through two single sweeps.)
+bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float *b, const float *a_prev,
+                          const float *c, const float *d, int nsrc) {
+  if (!g) return false;
+  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
+  if (ex < 1 || ez != M2_ZCELLS || ey < M2_ROWS || ey % M2_ROWS) return false;
+  if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
+  if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
+  if (((long)g->nyp * g->nzp) % 4) return false;
+  // the kernel touches planes x_m-4 .. x_M+4 and rows y_m-4 .. y_M+4 of the padded arrays
+  if (g->x_m < 0 || g->x_M + FDTD_HALO + 4 > g->nxp - 1) return false;
+  if (g->y_m < 0 || g->y_M + FDTD_HALO + 4 > g->nyp - 1) return false;
+  if (g->z_M + FDTD_HALO + 2 > g->nzp - 1) return false;
+  if (nsrc > M2_MAX_SRC) return false;
+  return true;
+}
+
+// Two steps (time, time + 1) on four level buffers: cur = u(time), prev = u(time-1) are read,
+// next1 = u(time+1) and next2 = u(time+2) are written (next1 and next2 keep their halos).  Both
+// source scatters are included.  Fused into one sweep when the shape allows, otherwise run as
+// two sweeps; the result is the same bit for bit.
+// `mid`, when not null, is recorded after the second sweep and before the second scatter.
+int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
+                        const float *src_coords, const float *cur, const float *prev, float *next1,
+                        float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                        int variant, void *stream, hipEvent_t mid) {
+  if (!g || !m || !cur || !prev || !next1 || !next2) return (int)hipErrorInvalidValue;
+  const bool has_src = p_src_M >= p_src_m;
+  if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
+  const int nsrc = has_src ? p_src_M - p_src_m + 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1;
+  // Launch shape: one workgroup per CU (the LDS of a CU holds one tile), nyt y-tiles times as
+  // many x-chunks as fill 256 workgroups; long x ranges are cut into several launches so that
+  // workgroups march at most ~128 planes side by side (they drift apart beyond that and stop
+  // finding each other's rows in L2).
+  const int nyt = ey / M2_ROWS > 0 ? ey / M2_ROWS : 1;
+  const int nxc = nyt >= 256 ? 1 : (256 + nyt / 2) / nyt;
+  int xchunk = env_int2("FDTD_FUSE2_XCHUNK", 0);
+  if (xchunk <= 0) {
+    const int per_launch_cap = 128;
+    xchunk = (ex + nxc - 1) / nxc;
+    if (xchunk > per_launch_cap) {
+      const int launches = (ex + nxc * per_launch_cap - 1) / (nxc * per_launch_cap);
+      xchunk = (ex + nxc * launches - 1) / (nxc * launches);
+    }
+    if (xchunk < 16) xchunk = ex < 16 ? (ex > 0 ? ex : 1) : 16;   // each chunk recomputes 4 planes of C
+  }
+  // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
+  const bool offsets_ok = (long)(xchunk + 9) * g->nyp * g->nzp * 4 < (1L << 31);
+  const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
+                    env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok &&
+                    fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
+                    (variant == FDTD_VARIANT_MARCH2 || ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32));
+  if (!fuse) {
+    const int v1 = variant == FDTD_VARIANT_MARCH2 ? FDTD_VARIANT_AUTO : variant;
+    int rc = fdtd_stencil_levels(g, m, cur, prev, next1, v1, stream);
+    if (rc) return rc;
+    if (has_src) {
+      rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                             g->x_m - 1, g->x_M + 1, 0, stream);
+      if (rc) return rc;
+    }
+    rc = fdtd_stencil_levels(g, m, next1, cur, next2, v1, stream);
+    if (rc) return rc;
+    if (mid) FDTD_HIP_CHECK(hipEventRecord(mid, s));
+    if (has_src)
+      rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                             g->x_m - 1, g->x_M + 1, 0, stream);
+    return rc;
+  }
+
+  // corners of the first scatter that land in the halo layer of next1: applied to memory first
+  // (the sweep never writes there and reads them like any other halo value)
+  if (has_src) {
+    const int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
+                                     0, g->x_m - 1, g->x_M + 1, 1, stream);
+    if (rc) return rc;
+  }
+  March2Args a;
+  a.B = (const char *)cur; a.A = (const char *)prev; a.m = (const char *)m;
+  a.C = (char *)next1; a.D = (char *)next2;
+  a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
+  a.x_m = a.dx_m = g->x_m; a.x_M = a.dx_M = g->x_M;
+  a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
+  a.k.cm2 = -8.33333333e-2F; a.k.cm1 = 1.333333330F; a.k.c0 = -2.50F;
+  a.k.dt2 = g->dt * g->dt;
+  a.k.r1 = 1.0F / (g->dt * g->dt);
+  a.k.r2 = 1.0F / (g->h_x * g->h_x);
+  a.k.r3 = 1.0F / (g->h_y * g->h_y);
+  a.k.r4 = 1.0F / (g->h_z * g->h_z);
+  a.k.neg2r1 = -2.0F * a.k.r1;
+  a.src_row = has_src ? src + (long)time * src_stride : nullptr;
+  a.coords = src_coords; a.m_f = m;
+  a.nsrc = nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride;
+  a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
+
+  const bool nt = env_int2("FDTD_NT", 1) != 0;
+  // several launches of nxc chunks each
+  for (int x0 = g->x_m; x0 <= g->x_M; x0 += nxc * xchunk) {
+    March2Args al = a;
+    al.x_m = x0;
+    al.x_M = x0 + nxc * xchunk - 1 < g->x_M ? x0 + nxc * xchunk - 1 : g->x_M;
+    const int chunks = (al.x_M - al.x_m + xchunk) / xchunk;
+    if (nt)
+      hipLaunchKernelGGL((stencil_march2_kernel<true>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
+    else
+      hipLaunchKernelGGL((stencil_march2_kernel<false>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
+  }
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  if (mid) FDTD_HIP_CHECK(hipEventRecord(mid, s));
+  if (has_src)
+    rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                           g->x_m - 1, g->x_M + 1, 0, stream);
+  return rc;
+}
+
+extern "C" int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
+                                  const float *src_coords, const float *cur, const float *prev,
+                                  float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                                  int src_stride, int coord_stride, int variant, void *stream) {
+  return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
+                             coord_stride, variant, stream, nullptr);
+}
+
+// One step (sweep + scatter) on explicit level buffers: the single-step companion of
+// fdtd_hip_two_steps for callers that rotate four buffers.
+extern "C" int fdtd_hip_one_step(const struct fdtd_geom *g, const float *m, const float *src,
+                                 const float *src_coords, const float *cur, const float *prev, float *next,
+                                 int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                                 int variant, void *stream) {
+  if (!g || !m || !cur || !prev || !next) return (int)hipErrorInvalidValue;
+  const bool has_src = p_src_M >= p_src_m;
+  if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
+  int rc = fdtd_stencil_levels(g, m, cur, prev, next, variant, stream);
+  if (rc || !has_src) return rc;
+  return fdtd_inject_level(g, m, src, src_coords, next, time, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                           g->x_m - 1, g->x_M + 1, 0, stream);
+}
+
+// Copies the shell (mode 1) or the shell and the box (mode 0) of one level into another.  A time
+// loop that rotates more than three level buffers uses it to give the buffer that receives
+// u(t+2) the shell of u(t-1), which is what writing u(t+2) over u(t-1) in a ring of three keeps.
+extern "C" int fdtd_hip_copy_shell(const struct fdtd_geom *g, float *dst_level, const float *src_level,
+                                   int with_box, void *stream) {
+  if (!g || !dst_level || !src_level) return (int)hipErrorInvalidValue;
+  if (g->x_M < g->x_m || g->y_M < g->y_m || g->z_M < g->z_m) return 0;
+  return launch_shell(g, dst_level, src_level, nullptr, nullptr, with_box ? 0 : 1, (hipStream_t)stream);
+}
+
+// *flag (device int, zeroed by the caller) is set when the shells of the two levels differ.
+int fdtd_shells_differ(const struct fdtd_geom *g, const float *a, const float *b, int *flag, void *stream) {
+  return launch_shell(g, nullptr, a, b, flag, 2, (hipStream_t)stream);
+}

@@ -9,6 +9,7 @@
 //                           copy all of u back; free every device buffer before return
 //   cuda.cu:246,288         sources are injected iff p_src_M >= p_src_m
 //   openacc.cpp:3           timers are accumulated, in seconds
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,6 +46,154 @@ struct EventPool {
 
 }  // namespace
 
+// The time loop with two steps per sweep (fp32 storage).  Four level buffers rotate: the three
+// slots of `u` and one more level allocated here.  Roles: cur = u(t), prev = u(t-1),
+// third = u(t-2), spare.  A single step writes u(t+1) over third (the reference's ring,
+// openacc.cpp:148); a fused pair writes u(t+1) over third and u(t+2) into spare.
+//
+// Halo cells belong to ring slots in the reference: u(t+2) overwrites the slot of u(t-1) and
+// from then on is surrounded by that slot's halo, including whatever source corners have been
+// scattered into it (openacc.cpp:192 admits one cell beyond every face).  Rotating four buffers
+// keeps that behaviour by copying the shell of prev into spare before each pair; the copies are
+// skipped when the three slots start with identical shells and no source corner can land in the
+// halo layer.  At the end box and shell of the three newest levels go back to the slots the
+// ring leaves them in; padding further out is never read or written and stays as the caller
+// gave it.
+static int time_loop_fused(const struct fdtd_geom *g, const float *m, const float *src,
+                           const float *src_coords, float *u, int p_src_m, int p_src_M, int src_stride,
+                           int coord_stride, int time_m, int time_M, int variant, hipStream_t s,
+                           struct profiler *timers, bool has_src) {
+  const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
+  struct Owned {
+    float *level = nullptr;
+    int *flag = nullptr;
+    ~Owned() {
+      if (level) (void)hipFree(level);
+      if (flag) (void)hipFree(flag);
+    }
+  } own;
+  FDTD_HIP_CHECK(hipMalloc((void **)&own.level, vol * sizeof(float)));
+  FDTD_HIP_CHECK(hipMalloc((void **)&own.flag, sizeof(int)));
+  float *P[4] = {u, u + vol, u + 2 * vol, own.level};
+  auto mod3 = [](int t) { return ((t % 3) + 3) % 3; };
+  int cur = mod3(time_m), prev = mod3(time_m + 2), third = mod3(time_m + 1), spare = 3;
+
+  // do shells have to follow the ring?
+  bool follow = false;
+  if (has_src) {
+    const int nsrc = p_src_M - p_src_m + 1;
+    std::vector<float> hc((size_t)nsrc * coord_stride);
+    FDTD_HIP_CHECK(hipMemcpyAsync(hc.data(), src_coords + (size_t)p_src_m * coord_stride, hc.size() * sizeof(float),
+                                  hipMemcpyDeviceToHost, s));
+    FDTD_HIP_CHECK(hipStreamSynchronize(s));
+    for (int p = 0; p < nsrc && !follow; ++p) {
+      // positions as openacc.cpp:185-187 computes them
+      const int posx = (int)floorf((-g->o_x + hc[(size_t)p * coord_stride + 0]) / g->h_x);
+      const int posy = (int)floorf((-g->o_y + hc[(size_t)p * coord_stride + 1]) / g->h_y);
+      const int posz = (int)floorf((-g->o_z + hc[(size_t)p * coord_stride + 2]) / g->h_z);
+      follow = posx < g->x_m || posx + 1 > g->x_M || posy < g->y_m || posy + 1 > g->y_M || posz < g->z_m ||
+               posz + 1 > g->z_M;
+    }
+  }
+  if (!follow) {
+    int differ = 0;
+    FDTD_HIP_CHECK(hipMemsetAsync(own.flag, 0, sizeof(int), s));
+    int rc = fdtd_shells_differ(g, P[0], P[1], own.flag, s);
+    if (rc) return rc;
+    rc = fdtd_shells_differ(g, P[1], P[2], own.flag, s);
+    if (rc) return rc;
+    FDTD_HIP_CHECK(hipMemcpyAsync(&differ, own.flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    FDTD_HIP_CHECK(hipStreamSynchronize(s));
+    follow = differ != 0;
+    if (!follow) {   // one shell for everybody
+      rc = fdtd_hip_copy_shell(g, P[3], P[0], 0, s);
+      if (rc) return rc;
+    }
+  }
+
+  const int first_timed = time_m + FDTD_WARMUP_STEPS;
+  const int n_timed = (timers && time_M >= first_timed) ? (time_M - first_timed + 1) : 0;
+  EventPool pool;
+  if (n_timed > 0) {
+    int rc = pool.make((size_t)n_timed * 3);
+    if (rc) return rc;
+  }
+  int nev = 0;   // events are recorded in triples: start, end of section0, end of section1
+  const int single = variant == FDTD_VARIANT_MARCH2 ? FDTD_VARIANT_AUTO : variant;
+  int time = time_m;
+  while (time <= time_M) {
+    const bool timed = n_timed > 0 && time >= first_timed;
+    // a pair must not straddle the start of the timed window
+    const bool pair = time + 1 <= time_M && !(n_timed > 0 && time < first_timed && time + 1 >= first_timed);
+    if (timed) FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev], s));
+    if (pair) {
+      if (follow) {
+        const int rc = fdtd_hip_copy_shell(g, P[spare], P[prev], 0, s);
+        if (rc) return rc;
+      }
+      const int rc = fdtd_two_steps_impl(g, m, has_src ? src : nullptr, has_src ? src_coords : nullptr, P[cur],
+                                         P[prev], P[third], P[spare], time, has_src ? p_src_m : 0,
+                                         has_src ? p_src_M : -1, src_stride, coord_stride, variant, s,
+                                         timed ? pool.ev[nev + 1] : nullptr);
+      if (rc) return rc;
+      const int ncur = spare, nprev = third, nthird = cur, nspare = prev;
+      cur = ncur; prev = nprev; third = nthird; spare = nspare;
+      time += 2;
+    } else {
+      int rc = fdtd_stencil_levels(g, m, P[cur], P[prev], P[third], single, s);
+      if (rc) return rc;
+      if (timed) FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev + 1], s));
+      if (has_src) {
+        rc = fdtd_inject_level(g, m, src, src_coords, P[third], time, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                               g->x_m - 1, g->x_M + 1, 0, s);
+        if (rc) return rc;
+      }
+      const int ncur = third, nprev = cur, nthird = prev;
+      cur = ncur; prev = nprev; third = nthird;
+      time += 1;
+    }
+    if (timed) {
+      FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev + 2], s));
+      nev += 3;
+    }
+  }
+  // u(T+1), u(T), u(T-1) (T = time_M) go where the reference's ring leaves them; the free buffer
+  // is the scratch cell of the permutation
+  {
+    int pos[3] = {cur, prev, third};
+    const int tgt[3] = {mod3(time_M + 1), mod3(time_M), mod3(time_M + 2)};
+    int free_pos = spare;
+    for (int it = 0; it < 8; ++it) {
+      int mover = -1;
+      for (int r = 0; r < 3; ++r)
+        if (pos[r] != tgt[r] && tgt[r] == free_pos) mover = r;
+      if (mover < 0)
+        for (int r = 0; r < 3; ++r)
+          if (pos[r] != tgt[r]) mover = r;
+      if (mover < 0) break;
+      const int rc = fdtd_hip_copy_shell(g, P[free_pos], P[pos[mover]], 1, s);
+      if (rc) return rc;
+      const int old = pos[mover];
+      pos[mover] = free_pos;
+      free_pos = old;
+    }
+  }
+  FDTD_HIP_CHECK(hipStreamSynchronize(s));
+  if (n_timed > 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < nev; k += 3) {
+      float ms0 = 0.f, ms1 = 0.f;
+      FDTD_HIP_CHECK(hipEventElapsedTime(&ms0, pool.ev[k], pool.ev[k + 1]));
+      FDTD_HIP_CHECK(hipEventElapsedTime(&ms1, pool.ev[k + 1], pool.ev[k + 2]));
+      s0 += ms0;
+      s1 += ms1;
+    }
+    timers->section0 += s0 * 1e-3;
+    timers->section1 += s1 * 1e-3;
+  }
+  return 0;
+}
+
 // `h16` selects the binary16-storage kernels; u then points at __half data.
 static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, const float *src,
                           const float *src_coords, void *u, int p_src_m, int p_src_M,
@@ -54,6 +203,20 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
   hipStream_t s = (hipStream_t)stream;
   const bool has_src = (p_src_M >= p_src_m) && src && src_coords;
   if (p_src_M >= p_src_m && !has_src) return (int)hipErrorInvalidValue;
+
+  // two steps per sweep when the shape allows it and there are enough steps to pay for the
+  // extra level buffer
+  if (!h16 && (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) && time_M - time_m + 1 >= 4) {
+    const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
+    float *uf = (float *)u;
+    const char *e = getenv("FDTD_FUSE2");
+    const int ex = g->x_M - g->x_m + 1;
+    if ((!e || atoi(e) != 0) && (variant == FDTD_VARIANT_MARCH2 || ex >= 32) &&
+        fdtd_march2_eligible(g, m, uf, uf + vol, uf + 2 * vol, uf, has_src ? p_src_M - p_src_m + 1 : 0))
+      return time_loop_fused(g, m, src, src_coords, uf, p_src_m, p_src_M, src_stride, coord_stride, time_m,
+                             time_M, variant, s, timers, has_src);
+  }
+  if (variant == FDTD_VARIANT_MARCH2) variant = FDTD_VARIANT_AUTO;
 
   // Three events per timed step: before the stencil, between the sections, after the
   // scatter.  They are recorded on the stream without any host synchronisation; the
@@ -223,6 +386,7 @@ static int optimized_variant() {
   if (!strcmp(v, "march")) return FDTD_VARIANT_MARCH;
   if (!strcmp(v, "tile3d")) return FDTD_VARIANT_TILE3D;
   if (!strcmp(v, "vec")) return FDTD_VARIANT_VEC;
+  if (!strcmp(v, "march2")) return FDTD_VARIANT_MARCH2;
   return FDTD_VARIANT_AUTO;
 }
 

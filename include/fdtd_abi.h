@@ -114,6 +114,7 @@ enum fdtd_variant {
   FDTD_VARIANT_MARCH = 2,    /* x-marching, register column + LDS centre plane      */
   FDTD_VARIANT_TILE3D = 3,   /* 8x8x8 outputs from a 12x12x12 LDS tile              */
   FDTD_VARIANT_VEC = 4,      /* one-shot float4 lanes, cache-ordered launch          */
+  FDTD_VARIANT_MARCH2 = 5,   /* two time steps per sweep (fdtd_hip_two_steps and the time loop only) */
   FDTD_VARIANT_AUTO = -1     /* MARCH when the shape allows it, else NAIVE          */
 };
 
@@ -153,6 +154,39 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
                                 int t2, int time, int p_src_m, int p_src_M,
                                 int src_stride, int coord_stride, int x_shift, int x_lo,
                                 int x_hi, void *stream);
+
+/* Two time steps (time and time + 1) in one call, on four separate level buffers of
+ * nxp*nyp*nzp floats each: cur = u(time) and prev = u(time-1) are read, next1 =
+ * u(time+1) and next2 = u(time+2) are written (interior cells only; the halo cells of
+ * next1 and next2 keep their values and are read as such).  Both source scatters are
+ * included.  When the shape allows (z extent 512, y extent a multiple of 8, at most 8
+ * sources) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
+ * per cell update; otherwise they run one after the other.  Either way the result is
+ * bit for bit that of two single steps.  This is the time fusion the reference driver
+ * has a knob for (t_fuse, main.cpp:261,267) and no reference kernel implements.
+ * next2 must not alias prev.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
+ * the fusion, any other variant selects the single-step kernel used for both sweeps. */
+int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
+                       const float *src_coords, const float *cur, const float *prev,
+                       float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                       int src_stride, int coord_stride, int variant, void *stream);
+
+/* One step (sweep of openacc.cpp:151-168 + scatter of openacc.cpp:173-203) on three separate
+ * level buffers: next = u(time+1) from cur = u(time) and prev = u(time-1). */
+int fdtd_hip_one_step(const struct fdtd_geom *g, const float *m, const float *src,
+                      const float *src_coords, const float *cur, const float *prev, float *next,
+                      int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                      int variant, void *stream);
+
+/* Copies the shell of one level buffer into another: the two layers of cells around the
+ * updated box, which is every halo cell a sweep reads (openacc.cpp:161-163) or a scatter
+ * touches (openacc.cpp:192); with_box != 0 copies the box as well.  In the reference's ring
+ * of three, u(t+2) is written over u(t-1) and inherits its halo; a caller that rotates four
+ * buffers through fdtd_hip_two_steps gets the same values by copying the shell of prev into
+ * next2 before the call (unnecessary when all buffers hold the same halo, e.g. zeros, and
+ * no source sits in the outermost cell layer). */
+int fdtd_hip_copy_shell(const struct fdtd_geom *g, float *dst_level, const float *src_level,
+                        int with_box, void *stream);
 
 /* The whole time loop on device-resident fields: steps time_m..time_M, ring
  * indexing and section timers exactly as the operators do (timers may be NULL, in

@@ -45,6 +45,14 @@ CASES = {
     # time_M < time_m: nothing happens at all
     "zero_steps": ("random", dict(n=(12, 12, 16), nt=4, nsrc=1, h=(1.0, 1.0, 1.0), seed=21, time_m=3,
                                   time_M_override=2)),
+    # z extent 512, y extent a multiple of 8, at least 32 planes: the two-steps-per-sweep kernel.
+    # Random fields carry a different halo in each ring level, so the shells have to follow the ring;
+    # the second case adds a source in the outermost cell (scatter into the halo layer) and a time offset;
+    # the third has zero halos throughout (no shell copies) and the largest number of sources the fused sweep takes.
+    "fused_z512": ("random", dict(n=(40, 16, 512), nt=11, nsrc=3, h=(1.0, 0.9, 1.1), seed=22)),
+    "fused_z512_edge_source": ("random", dict(n=(36, 24, 512), nt=17, nsrc=2, h=(0.8, 1.0, 1.25), seed=23,
+                                              edge_source=True, time_m=7)),
+    "fused_z512_ricker8": ("ricker", dict(n=(34, 16, 512), nt=14, nsrc=8)),
     "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
     "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
 }

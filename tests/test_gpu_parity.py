@@ -215,6 +215,61 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
     check_against_golden("noncubic_aniso", u_d.cpu().numpy(), exact=True)
 
 
+@pytest.mark.parametrize("shape,nsrc,variant", [((70, 64, 512), 3, "auto"), ((20, 16, 512), 2, "march2"),
+                                                ((24, 8, 512), 0, "march2"), ((520, 512, 512), 1, "auto")])
+def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant):
+    """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
+    oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
+    one launch, forced fusion on a short x range, no sources, and an x range long enough to be cut
+    into two launches (520 planes at 64 y-tiles)."""
+    import torch
+    nx, ny, nz = shape
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    pshape = (nx + 8, ny + 8, nz + 8)
+    lv = [torch.rand(pshape, device="cuda", generator=gen) * 2 - 1 for _ in range(4)]
+    lv[1] = lv[0] + 0.01 * lv[1]
+    m = torch.rand(pshape, device="cuda", generator=gen) * 2 + 1
+    h = (0.9, 1.0, 1.1)
+    g = pkg.Geom(*pshape, 0, nx - 1, 0, ny - 1, 0, nz - 1, 1e-3, *h, 0.0, 0.0, 0.0)
+    src = coords = None
+    if nsrc:
+        src = (torch.rand((4, nsrc), device="cuda", generator=gen) * 100 - 50)
+        ext = torch.tensor([(nx - 1) * h[0], (ny - 1) * h[1], (nz - 1) * h[2]], device="cuda")
+        coords = (torch.rand((nsrc, 3), device="cuda", generator=gen) * 0.9 + 0.05) * ext
+        coords[0] = torch.tensor([(nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2]])   # corners in the halo layer
+
+    def run(var):
+        cur, prev, n1, n2 = (t.clone() for t in lv)
+        rc = hiplib.fdtd_hip_two_steps(C.byref(g), m.data_ptr(), src.data_ptr() if nsrc else None,
+                                       coords.data_ptr() if nsrc else None, cur.data_ptr(), prev.data_ptr(),
+                                       n1.data_ptr(), n2.data_ptr(), 1, 0, nsrc - 1, max(nsrc, 1), 3,
+                                       pkg.VARIANTS[var], None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return n1, n2
+
+    f1, f2 = run(variant)
+    s1, s2 = run("naive")
+    assert torch.equal(f1.view(torch.int32), s1.view(torch.int32))
+    assert torch.equal(f2.view(torch.int32), s2.view(torch.int32))
+    assert not torch.equal(f2, lv[3])
+
+
+def test_fused_time_loop_switch(pkg, hiplib, monkeypatch):
+    """The time loop with and without the two-step sweep gives the same bytes as the oracle: Ricker run
+    at 64 x 64 x 512, 50 steps (5 untimed single steps, 22 pairs, 1 single step), timers filled."""
+    n = (64, 64, 512)
+    u_ref, m, src, coords = pkg.standard_inputs(*n, 50, 1)
+    ob.run_oracle(m, src, coords, u_ref)
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FDTD_FUSE2", fuse)
+        u = np.zeros_like(u_ref)
+        rc, prof = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u)
+        assert rc == 0
+        assert ob.bits_equal(u, u_ref), f"FDTD_FUSE2={fuse}"
+        assert prof.section0 > 0 and prof.section1 > 0
+
+
 def test_run_wrappers(pkg, hiplib):
     """run_openacc / run_cuda / run_cuda_optimized with the standard benchmark inputs."""
     n, nt = 32, 50

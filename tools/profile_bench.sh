@@ -14,16 +14,20 @@ python3 - "$O" <<'PY'
 import csv, glob, collections, json, sys
 O = sys.argv[1]
 out = {}
+rows = list(csv.DictReader(open(glob.glob(f"{O}/fetch/*/*_counter_collection.csv")[0])))
+# the dominant kernel: the two-step sweep when bench.py used it, else the marching kernel
+kname = "stencil_march2" if any("stencil_march2" in r["Kernel_Name"] for r in rows) else "stencil_march_lds"
+out["kernel"] = kname
 for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = glob.glob(f"{O}/{d}/*/*_counter_collection.csv")[0]
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "stencil_march" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
     out[c + "_KB_per_launch"] = sum(vals) / len(vals)
     out[c + "_launches"] = len(vals)
 # gfx950: FETCH_SIZE reports half of the bytes of a wide coalesced streaming read; WRITE_SIZE is exact
 out["hbm_read_bytes_per_launch"] = 2 * 1024 * out["FETCH_SIZE_KB_per_launch"]
 out["hbm_write_bytes_per_launch"] = 1024 * out["WRITE_SIZE_KB_per_launch"]
 out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
-out["algorithmic_bytes_per_launch"] = 16 * 512 ** 3
+out["algorithmic_bytes_per_launch"] = (32 if kname == "stencil_march2" else 16) * 512 ** 3
 out["note"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); separate --pmc passes"
 json.dump(out, open(f"{O}/traffic.json", "w"), indent=1)
 print(json.dumps(out))
