@@ -60,4 +60,4 @@ int fdtd_shells_differ(const struct fdtd_geom *g, const float *a, const float *b
 int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
-                        int variant, void *stream, hipEvent_t mid);
+                        int variant, int flags, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end);

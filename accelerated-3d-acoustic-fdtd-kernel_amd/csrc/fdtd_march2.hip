@@ -57,7 +57,8 @@ struct March2Args {
   int y_m, y_M, z_m;
   Coef2 k;
   // source scatter of the first step (time index `time`), applied to C between the two updates
-  const float *src_row;   // src + time * src_stride
+  const float *src_row;   // src + time * src_stride: amplitudes of the first scatter (into C)
+  const float *src_row2;  // src + (time + 1) * src_stride: second scatter (into D)
   const float *coords;
   const float *m_f;
   int nsrc, p_src_m, coord_stride;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   // ---- source corners of the first step: lane l holds corner l (source l / 8, corner l % 8) ----
   bool cvalid = false;
   int cx = 0, cy = 0, cz = 0;
-  float cval = 0.f;
+  float cval = 0.f, cval2 = 0.f;
   if (lane < a.nsrc * 8) {
     const int p = a.p_src_m + (lane >> 3);
     const int rx = (lane >> 2) & 1, ry = (lane >> 1) & 1, rz = lane & 1;
@@ -188,11 +189,32 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     cx = rx + posx; cy = ry + posy; cz = rz + posz;
     // corners that land in the first halo layer are applied to memory before the launch
     cvalid = cx >= a.dx_m && cx <= a.dx_M && cy >= a.y_m && cy <= a.y_M && cz >= a.z_m && cz <= a.z_M;
-    if (cvalid)
-      cval = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
-             (rz * pz + (1 - rz) * (1 - pz)) * a.src_row[p] /
-             a.m_f[(long)(posx + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy + (posz + FDTD_HALO)];
+    if (cvalid) {
+      // openacc.cpp:194 evaluates left to right: the weight product is common to both time steps
+      const float w = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
+                      (rz * pz + (1 - rz) * (1 - pz));
+      const float mc = a.m_f[(long)(posx + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy + (posz + FDTD_HALO)];
+      cval = w * a.src_row[p] / mc;
+      cval2 = w * a.src_row2[p] / mc;
+    }
   }
+  // adds the corners of one scatter that fall on row `yr` of plane-mask `mask` to a row segment
+  auto scatter_into = [&](f32x4 &v, unsigned long mask, float val, int yr) __attribute__((always_inline)) {
+    while (mask) {   // wave-uniform; lane order = source order = the reference's loop order
+      const int b = __builtin_ctzl(mask);
+      mask &= mask - 1;
+      const int sy_ = __builtin_amdgcn_readlane(cy, b), sz_ = __builtin_amdgcn_readlane(cz, b);
+      const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), b));
+      const int zi = sz_ - a.z_m;
+      const bool hit = sy_ == yr && (zi >> 2) == lz;
+      const int comp = zi & 3;
+      const f32x4 added = v + f32x4{sv, sv, sv, sv};
+      v.x = (hit && comp == 0) ? added.x : v.x;
+      v.y = (hit && comp == 1) ? added.y : v.y;
+      v.z = (hit && comp == 2) ? added.z : v.z;
+      v.w = (hit && comp == 3) ? added.w : v.w;
+    }
+  };
 
 #define LD4(r, so, off) ld4<false>(r, so, off)
 #define LD4S(r, so, off) ld4<NT>(r, so, off)
@@ -250,7 +272,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     const bool store_c = STEADY ? true : (plane_inside && p >= x_begin && p <= x_end);
     const int d = p - 2;
     const bool do_d = STEADY ? true : (d >= x_begin && d <= x_end);
-    const unsigned long cmask = __ballot(cvalid && cx == p);   // corners of the first step in this plane
+    const unsigned long cmask = __ballot(cvalid && cx == p);       // corners of the first scatter in plane p
+    const unsigned long dmask = __ballot(cvalid && cx == p - 2);   // corners of the second scatter in plane p-2
 
     auto compute = [&](auto seg) __attribute__((always_inline)) {
       constexpr int s = decltype(seg)::value;
@@ -263,23 +286,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
         cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
                           mv[s]);
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
-        if (cmask) {   // wave-uniform; source order = lane order = the reference's loop order
-          unsigned long mm = cmask;
-          while (mm) {
-            const int b = __builtin_ctzl(mm);
-            mm &= mm - 1;
-            const int sy_ = __builtin_amdgcn_readlane(cy, b), sz_ = __builtin_amdgcn_readlane(cz, b);
-            const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cval), b));
-            const int zi = sz_ - a.z_m;
-            const bool hit = sy_ == yrow[s] && (zi >> 2) == lz;
-            const int comp = zi & 3;
-            const f32x4 added = cnew + f32x4{sv, sv, sv, sv};
-            cnew.x = (hit && comp == 0) ? added.x : cnew.x;
-            cnew.y = (hit && comp == 1) ? added.y : cnew.y;
-            cnew.z = (hit && comp == 2) ? added.z : cnew.z;
-            cnew.w = (hit && comp == 3) ? added.w : cnew.w;
-          }
-        }
+        if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
       } else {   // halo plane of the domain: the intermediate level keeps what memory holds there
         cnew = LD4(rC, sp, voff[s]);
       }
@@ -295,8 +302,9 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
           const f32x4 nb = Cring[ring_r][r][h ? 63 : 64];   // the other z-half of the same row
           const f32x2 eL = h ? f32x2{nb.z, nb.w} : ce[s];
           const f32x2 eR = h ? ce[s] : f32x2{nb.x, nb.y};
-          const f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
-                                     PB(0)[s], mh[0][s]);
+          f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
+                               PB(0)[s], mh[0][s]);
+          if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
           st4<NT>(rD, sp - 2 * sxb, voff[s], o);
         }
         if (STEADY) {
@@ -448,11 +456,13 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
 // next1 = u(time+1) and next2 = u(time+2) are written (next1 and next2 keep their halos).  Both
 // source scatters are included.  Fused into one sweep when the shape allows, otherwise run as
 // two sweeps; the result is the same bit for bit.
-// `mid`, when not null, is recorded after the second sweep and before the second scatter.
+// ev_begin / ev_end, when not null, are recorded right before the first and right after the last
+// sweep kernel.  flags bit 0: the caller guarantees that no source corner lands in the halo layer
+// (the two small launches that serve such corners are skipped).
 int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
-                        int variant, void *stream, hipEvent_t mid) {
+                        int variant, int flags, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
   if (!g || !m || !cur || !prev || !next1 || !next2) return (int)hipErrorInvalidValue;
   const bool has_src = p_src_M >= p_src_m;
   if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
@@ -483,6 +493,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
                     (variant == FDTD_VARIANT_MARCH2 || ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32));
   if (!fuse) {
     const int v1 = variant == FDTD_VARIANT_MARCH2 ? FDTD_VARIANT_AUTO : variant;
+    if (ev_begin) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
     int rc = fdtd_stencil_levels(g, m, cur, prev, next1, v1, stream);
     if (rc) return rc;
     if (has_src) {
@@ -492,20 +503,25 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     }
     rc = fdtd_stencil_levels(g, m, next1, cur, next2, v1, stream);
     if (rc) return rc;
-    if (mid) FDTD_HIP_CHECK(hipEventRecord(mid, s));
+    if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
     if (has_src)
       rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
                              g->x_m - 1, g->x_M + 1, 0, stream);
     return rc;
   }
 
-  // corners of the first scatter that land in the halo layer of next1: applied to memory first
-  // (the sweep never writes there and reads them like any other halo value)
-  if (has_src) {
-    const int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
-                                     0, g->x_m - 1, g->x_M + 1, 1, stream);
+  // Both scatters happen inside the sweep for corners that land in the updated box.  Corners that
+  // land in the halo layer are applied to memory first: the sweep never writes there, and reads
+  // next1's halo like any other halo value.
+  if (has_src && !(flags & 1)) {
+    int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                               g->x_m - 1, g->x_M + 1, 1, stream);
+    if (rc) return rc;
+    rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
+                           g->x_m - 1, g->x_M + 1, 1, stream);
     if (rc) return rc;
   }
+  if (ev_begin) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
   March2Args a;
   a.B = (const char *)cur; a.A = (const char *)prev; a.m = (const char *)m;
   a.C = (char *)next1; a.D = (char *)next2;
@@ -520,6 +536,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.k.r4 = 1.0F / (g->h_z * g->h_z);
   a.k.neg2r1 = -2.0F * a.k.r1;
   a.src_row = has_src ? src + (long)time * src_stride : nullptr;
+  a.src_row2 = has_src ? src + (long)(time + 1) * src_stride : nullptr;
   a.coords = src_coords; a.m_f = m;
   a.nsrc = nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
@@ -536,13 +553,10 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     else
       hipLaunchKernelGGL((stencil_march2_kernel<false>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
   }
-  int rc = (int)hipGetLastError();
+  const int rc = (int)hipGetLastError();
   if (rc) return rc;
-  if (mid) FDTD_HIP_CHECK(hipEventRecord(mid, s));
-  if (has_src)
-    rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                           g->x_m - 1, g->x_M + 1, 0, stream);
-  return rc;
+  if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
+  return 0;
 }
 
 extern "C" int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
@@ -550,7 +564,16 @@ extern "C" int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, con
                                   float *next1, float *next2, int time, int p_src_m, int p_src_M,
                                   int src_stride, int coord_stride, int variant, void *stream) {
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, stream, nullptr);
+                             coord_stride, variant, 0, stream, nullptr, nullptr);
+}
+
+extern "C" int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float *src,
+                                     const float *src_coords, const float *cur, const float *prev,
+                                     float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                                     int src_stride, int coord_stride, int variant, int flags,
+                                     void *ev_begin, void *ev_end, void *stream) {
+  return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
+                             coord_stride, variant, flags, stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end);
 }
 
 // One step (sweep + scatter) on explicit level buffers: the single-step companion of

@@ -79,7 +79,7 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
   int cur = mod3(time_m), prev = mod3(time_m + 2), third = mod3(time_m + 1), spare = 3;
 
   // do shells have to follow the ring?
-  bool follow = false;
+  bool follow = false, sources_inside = true;
   if (has_src) {
     const int nsrc = p_src_M - p_src_m + 1;
     std::vector<float> hc((size_t)nsrc * coord_stride);
@@ -94,6 +94,7 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
       follow = posx < g->x_m || posx + 1 > g->x_M || posy < g->y_m || posy + 1 > g->y_M || posz < g->z_m ||
                posz + 1 > g->z_M;
     }
+    sources_inside = !follow;
   }
   if (!follow) {
     int differ = 0;
@@ -133,8 +134,8 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
       }
       const int rc = fdtd_two_steps_impl(g, m, has_src ? src : nullptr, has_src ? src_coords : nullptr, P[cur],
                                          P[prev], P[third], P[spare], time, has_src ? p_src_m : 0,
-                                         has_src ? p_src_M : -1, src_stride, coord_stride, variant, s,
-                                         timed ? pool.ev[nev + 1] : nullptr);
+                                         has_src ? p_src_M : -1, src_stride, coord_stride, variant,
+                                         sources_inside ? 1 : 0, s, nullptr, timed ? pool.ev[nev + 1] : nullptr);
       if (rc) return rc;
       const int ncur = spare, nprev = third, nthird = cur, nspare = prev;
       cur = ncur; prev = nprev; third = nthird; spare = nspare;

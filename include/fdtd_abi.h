@@ -171,6 +171,17 @@ int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *s
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,
                        int src_stride, int coord_stride, int variant, void *stream);
 
+/* The same with two extras for callers that measure or know more: ev_begin / ev_end
+ * (hipEvent_t, may be NULL) are recorded right before the first and right after the last
+ * sweep kernel; flags bit 0 (FDTD_TWO_STEPS_SOURCES_INSIDE) promises that no source corner
+ * lands in the halo layer, which saves the two small launches that serve such corners. */
+#define FDTD_TWO_STEPS_SOURCES_INSIDE 1
+int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float *src,
+                          const float *src_coords, const float *cur, const float *prev,
+                          float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                          int src_stride, int coord_stride, int variant, int flags,
+                          void *ev_begin, void *ev_end, void *stream);
+
 /* One step (sweep of openacc.cpp:151-168 + scatter of openacc.cpp:173-203) on three separate
  * level buffers: next = u(time+1) from cur = u(time) and prev = u(time-1). */
 int fdtd_hip_one_step(const struct fdtd_geom *g, const float *m, const float *src,
