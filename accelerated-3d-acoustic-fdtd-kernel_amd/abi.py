@@ -98,6 +98,11 @@ def lib():
     L.fdtd_hip_two_steps.restype = C.c_int
     L.fdtd_hip_two_steps_ex.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p] * 3
     L.fdtd_hip_two_steps_ex.restype = C.c_int
+    L.fdtd_hip_two_steps_slab.argtypes = ([C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 9
+                                          + [C.c_void_p, C.c_long, C.c_void_p])
+    L.fdtd_hip_two_steps_slab.restype = C.c_int
+    L.fdtd_hip_one_step_slab.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_void_p]
+    L.fdtd_hip_one_step_slab.restype = C.c_int
     L.fdtd_hip_one_step.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]
     L.fdtd_hip_one_step.restype = C.c_int
     L.fdtd_hip_copy_shell.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

@@ -35,7 +35,8 @@ struct InjectArgs {
   // is applied iff its GLOBAL x index lies in [x_lo, x_hi].  Single-domain calls use
   // x_shift = 0, x_lo = x_m - 1, x_hi = x_M + 1 (openacc.cpp:192).
   int x_shift, x_lo, x_hi;
-  int target_mode;  // 0: all admitted corners; 1: only those landing outside [x_m..x_M]x[y_m..y_M]x[z_m..z_M]
+  int target_mode;  // 0: all admitted corners; 1: only those landing outside the domain's box; 2: only inside
+  int gx_m, gx_M;   // planes of the domain's box in the coordinates of the source positions (target_mode != 0)
 };
 
 #define FDTD_HIP_CHECK(expr)                  \
@@ -51,7 +52,7 @@ int fdtd_stencil_levels(const struct fdtd_geom *g, const float *m, const float *
 int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *src,
                       const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
                       int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
-                      void *stream);
+                      int gx_m, int gx_M, void *stream);
 
 // fdtd_march2.hip: can the two-steps-per-sweep kernel take this problem?
 bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float *b, const float *a_prev,
@@ -60,4 +61,5 @@ int fdtd_shells_differ(const struct fdtd_geom *g, const float *a, const float *b
 int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
-                        int variant, int flags, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end);
+                        int variant, int flags, int x_shift, int global_nx, void *stream, hipEvent_t ev_begin,
+                        hipEvent_t ev_end, float *scratch, long scratch_floats);

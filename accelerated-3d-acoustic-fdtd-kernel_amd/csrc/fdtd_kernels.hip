@@ -593,11 +593,12 @@ __global__ __launch_bounds__(512) void stencil_tile3d_kernel(StencilArgs a, int 
 // sources that do not share cells the result does not depend on the order the atomics land in.
 // ---------------------------------------------------------------------------------
 // target_mode 1 keeps only the corners that land outside the updated box, i.e. in the first halo
-// layer (openacc.cpp:192 admits one cell beyond every face).
+// layer (openacc.cpp:192 admits one cell beyond every face); 2 keeps only those inside it.  The
+// box is the whole domain's: gx_m..gx_M are its planes in the coordinates of the source positions.
 __device__ __forceinline__ bool inject_target_selected(const InjectArgs &a, int x, int y, int z) {
   if (a.target_mode == 0) return true;
-  const bool inside = x >= a.x_m && x <= a.x_M && y >= a.y_m && y <= a.y_M && z >= a.z_m && z <= a.z_M;
-  return !inside;
+  const bool inside = x >= a.gx_m && x <= a.gx_M && y >= a.y_m && y <= a.y_M && z >= a.z_m && z <= a.z_M;
+  return a.target_mode == 1 ? !inside : inside;
 }
 
 __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
@@ -913,7 +914,7 @@ extern "C" int fdtd_hip_stencil_step(const struct fdtd_geom *g, const float *m, 
 int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *src,
                       const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
                       int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
-                      void *stream) {
+                      int gx_m, int gx_M, void *stream) {
   if (p_src_M < p_src_m) return 0;
   if (!g || !m || !src || !src_coords || !level || coord_stride < 3 || src_stride < 1)
     return (int)hipErrorInvalidValue;
@@ -922,6 +923,7 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
   a.m = m; a.src = src; a.coords = src_coords;
   a.u2 = level;
   a.target_mode = target_mode;
+  a.gx_m = gx_m; a.gx_M = gx_M;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
@@ -944,7 +946,7 @@ static int launch_inject(const struct fdtd_geom *g, const float *m, const float 
   if (!g || !u || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
   const long vol = (long)g->nxp * g->nyp * g->nzp;
   return fdtd_inject_level(g, m, src, src_coords, u + (long)t2 * vol, time, p_src_m, p_src_M, src_stride,
-                           coord_stride, x_shift, x_lo, x_hi, 0, stream);
+                           coord_stride, x_shift, x_lo, x_hi, 0, 0, 0, stream);
 }
 
 extern "C" int fdtd_hip_source_inject(const struct fdtd_geom *g, const float *m, const float *src,
@@ -1098,7 +1100,7 @@ extern "C" int fdtd_hip_source_inject_h16(const struct fdtd_geom *g, const float
   a.p_src_m = p_src_m; a.p_src_M = p_src_M; a.time = time;
   a.src_stride = src_stride; a.coord_stride = coord_stride;
   a.x_shift = 0; a.x_lo = g->x_m - 1; a.x_hi = g->x_M + 1;
-  a.target_mode = 0;
+  a.target_mode = 0; a.gx_m = g->x_m; a.gx_M = g->x_M;
   const long threads = (long)(p_src_M - p_src_m + 1) * 8;
   hipLaunchKernelGGL(source_inject_h16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, h);

@@ -63,6 +63,7 @@ struct March2Args {
   const float *m_f;
   int nsrc, p_src_m, coord_stride;
   int z_M;
+  int x_shift;        // source positions are in the coordinates of the whole domain: plane = position - x_shift
   float h_x, h_y, h_z, o_x, o_y, o_z;
 };
 
@@ -186,14 +187,17 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
     const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
     const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
-    cx = rx + posx; cy = ry + posy; cz = rz + posz;
-    // corners that land in the first halo layer are applied to memory before the launch
-    cvalid = cx >= a.dx_m && cx <= a.dx_M && cy >= a.y_m && cy <= a.y_M && cz >= a.z_m && cz <= a.z_M;
+    cx = rx + posx - a.x_shift; cy = ry + posy; cz = rz + posz;
+    // corners that land in the first halo layer are applied to memory before the launch; corners
+    // further than 2 planes from this launch's range concern other launches (or other ranks)
+    cvalid = cx >= a.dx_m && cx <= a.dx_M && cy >= a.y_m && cy <= a.y_M && cz >= a.z_m && cz <= a.z_M &&
+             cx >= a.x_m - 2 && cx <= a.x_M + 2;
     if (cvalid) {
       // openacc.cpp:194 evaluates left to right: the weight product is common to both time steps
       const float w = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
                       (rz * pz + (1 - rz) * (1 - pz));
-      const float mc = a.m_f[(long)(posx + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy + (posz + FDTD_HALO)];
+      const float mc = a.m_f[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
+                             (posz + FDTD_HALO)];
       cval = w * a.src_row[p] / mc;
       cval2 = w * a.src_row2[p] / mc;
     }
@@ -459,16 +463,31 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
 // ev_begin / ev_end, when not null, are recorded right before the first and right after the last
 // sweep kernel.  flags bit 0: the caller guarantees that no source corner lands in the halo layer
 // (the two small launches that serve such corners are skipped).
+//
+// Slab form (global_nx > 0): the arrays hold planes x_shift-4 .. of a domain of global_nx planes,
+// g->x_m..x_M is the local range to update, source positions are global.  u(time+1) is needed two
+// planes beyond the range on either side; inside the domain those planes are computed here as
+// well (from cur 4 planes and prev 2 planes beyond the range), bit for bit as their owner
+// computes them, and with the same source corners added.
 int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
-                        int variant, int flags, void *stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                        int variant, int flags, int x_shift, int global_nx, void *stream, hipEvent_t ev_begin,
+                        hipEvent_t ev_end, float *scratch, long scratch_floats) {
   if (!g || !m || !cur || !prev || !next1 || !next2) return (int)hipErrorInvalidValue;
   const bool has_src = p_src_M >= p_src_m;
   if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
   const int nsrc = has_src ? p_src_M - p_src_m + 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1;
+  if (ex <= 0) return 0;
+  // the domain's planes in local coordinates, and the planes whose halo-layer corners this call owns
+  const int dx_m = global_nx > 0 ? -x_shift : g->x_m, dx_M = global_nx > 0 ? global_nx - 1 - x_shift : g->x_M;
+  if (g->x_m < dx_m || g->x_M > dx_M) return (int)hipErrorInvalidValue;
+  const int own_lo = (g->x_m == dx_m ? g->x_m - 1 : g->x_m) + x_shift;
+  const int own_hi = (g->x_M == dx_M ? g->x_M + 1 : g->x_M) + x_shift;
+  const int gx_m = dx_m + x_shift, gx_M = dx_M + x_shift;
+
   // Launch shape: one workgroup per CU (the LDS of a CU holds one tile), nyt y-tiles times as
   // many x-chunks as fill 256 workgroups; long x ranges are cut into several launches so that
   // workgroups march at most ~128 planes side by side (they drift apart beyond that and stop
@@ -483,7 +502,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       const int launches = (ex + nxc * per_launch_cap - 1) / (nxc * per_launch_cap);
       xchunk = (ex + nxc * launches - 1) / (nxc * launches);
     }
-    if (xchunk < 16) xchunk = ex < 16 ? (ex > 0 ? ex : 1) : 16;   // each chunk recomputes 4 planes of C
+    if (xchunk < 16) xchunk = ex < 16 ? ex : 16;   // each chunk recomputes 4 planes of C
   }
   // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
   const bool offsets_ok = (long)(xchunk + 9) * g->nyp * g->nzp * 4 < (1L << 31);
@@ -491,42 +510,76 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
                     env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok &&
                     fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
                     (variant == FDTD_VARIANT_MARCH2 || ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32));
-  if (!fuse) {
+
+  // corners of either scatter that land in the halo layer: applied to memory by the call that owns
+  // their plane (the sweeps never write there and read next1's halo like any other halo value)
+  if (has_src && !(flags & 1)) {
+    int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
+                               x_shift, own_lo, own_hi, 1, gx_m, gx_M, stream);
+    if (rc) return rc;
+    rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
+                           x_shift, own_lo, own_hi, 1, gx_m, gx_M, stream);
+    if (rc) return rc;
+  }
+  if (ev_begin) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
+
+  const long plane = (long)g->nyp * g->nzp;
+  if (!fuse && scratch && scratch_floats >= (long)(ex + 4) * plane) {
+    // Thin range next to other ranges that are being updated at the same time (the boundary zone
+    // of a slab): u(time+1) on the range grown by two planes is built in `scratch`, so nothing is
+    // stored outside the range.  scratch plane j stands for plane x_m - 2 + j.
     const int v1 = variant == FDTD_VARIANT_MARCH2 ? FDTD_VARIANT_AUTO : variant;
-    if (ev_begin) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
-    int rc = fdtd_stencil_levels(g, m, cur, prev, next1, v1, stream);
+    float *c_lvl = scratch - (long)(g->x_m - 2 + FDTD_HALO) * plane;   // addressed like a level
+    FDTD_HIP_CHECK(hipMemcpyAsync(scratch, next1 + (long)(g->x_m - 2 + FDTD_HALO) * plane,
+                                  (size_t)(ex + 4) * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    fdtd_geom g1 = *g;
+    g1.x_m = g->x_m - 2 > dx_m ? g->x_m - 2 : dx_m;
+    g1.x_M = g->x_M + 2 < dx_M ? g->x_M + 2 : dx_M;
+    int rc = fdtd_stencil_levels(&g1, m, cur, prev, c_lvl, v1, stream);
     if (rc) return rc;
     if (has_src) {
-      rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                             g->x_m - 1, g->x_M + 1, 0, stream);
+      rc = fdtd_inject_level(g, m, src, src_coords, c_lvl, time, p_src_m, p_src_M, src_stride, coord_stride,
+                             x_shift, g1.x_m + x_shift, g1.x_M + x_shift, 2, gx_m, gx_M, stream);
+      if (rc) return rc;
+    }
+    rc = fdtd_stencil_levels(g, m, c_lvl, cur, next2, v1, stream);
+    if (rc) return rc;
+    FDTD_HIP_CHECK(hipMemcpyAsync(next1 + (long)(g->x_m + FDTD_HALO) * plane, scratch + 2 * plane,
+                                  (size_t)ex * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
+    if (has_src)
+      rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
+                             x_shift, g->x_m + x_shift, g->x_M + x_shift, 2, gx_m, gx_M, stream);
+    return rc;
+  }
+  if (!fuse) {
+    // two sweeps: the first over the range grown by two planes (inside the domain), with the
+    // corners inside the box added on all of those planes; the second over the range itself
+    const int v1 = variant == FDTD_VARIANT_MARCH2 ? FDTD_VARIANT_AUTO : variant;
+    fdtd_geom g1 = *g;
+    g1.x_m = g->x_m - 2 > dx_m ? g->x_m - 2 : dx_m;
+    g1.x_M = g->x_M + 2 < dx_M ? g->x_M + 2 : dx_M;
+    int rc = fdtd_stencil_levels(&g1, m, cur, prev, next1, v1, stream);
+    if (rc) return rc;
+    if (has_src) {
+      rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
+                             x_shift, g1.x_m + x_shift, g1.x_M + x_shift, 2, gx_m, gx_M, stream);
       if (rc) return rc;
     }
     rc = fdtd_stencil_levels(g, m, next1, cur, next2, v1, stream);
     if (rc) return rc;
     if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
     if (has_src)
-      rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                             g->x_m - 1, g->x_M + 1, 0, stream);
+      rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
+                             x_shift, g->x_m + x_shift, g->x_M + x_shift, 2, gx_m, gx_M, stream);
     return rc;
   }
 
-  // Both scatters happen inside the sweep for corners that land in the updated box.  Corners that
-  // land in the halo layer are applied to memory first: the sweep never writes there, and reads
-  // next1's halo like any other halo value.
-  if (has_src && !(flags & 1)) {
-    int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                               g->x_m - 1, g->x_M + 1, 1, stream);
-    if (rc) return rc;
-    rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                           g->x_m - 1, g->x_M + 1, 1, stream);
-    if (rc) return rc;
-  }
-  if (ev_begin) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
   March2Args a;
   a.B = (const char *)cur; a.A = (const char *)prev; a.m = (const char *)m;
   a.C = (char *)next1; a.D = (char *)next2;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
-  a.x_m = a.dx_m = g->x_m; a.x_M = a.dx_M = g->x_M;
+  a.x_m = g->x_m; a.x_M = g->x_M; a.dx_m = dx_m; a.dx_M = dx_M;
   a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.k.cm2 = -8.33333333e-2F; a.k.cm1 = 1.333333330F; a.k.c0 = -2.50F;
   a.k.dt2 = g->dt * g->dt;
@@ -538,9 +591,8 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.src_row = has_src ? src + (long)time * src_stride : nullptr;
   a.src_row2 = has_src ? src + (long)(time + 1) * src_stride : nullptr;
   a.coords = src_coords; a.m_f = m;
-  a.nsrc = nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride;
+  a.nsrc = nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride; a.x_shift = x_shift;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
-
   const bool nt = env_int2("FDTD_NT", 1) != 0;
   // several launches of nxc chunks each
   for (int x0 = g->x_m; x0 <= g->x_M; x0 += nxc * xchunk) {
@@ -564,7 +616,7 @@ extern "C" int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, con
                                   float *next1, float *next2, int time, int p_src_m, int p_src_M,
                                   int src_stride, int coord_stride, int variant, void *stream) {
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, 0, stream, nullptr, nullptr);
+                             coord_stride, variant, 0, 0, 0, stream, nullptr, nullptr, nullptr, 0);
 }
 
 extern "C" int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float *src,
@@ -573,7 +625,37 @@ extern "C" int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, 
                                      int src_stride, int coord_stride, int variant, int flags,
                                      void *ev_begin, void *ev_end, void *stream) {
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, flags, stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end);
+                             coord_stride, variant, flags, 0, 0, stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end,
+                             nullptr, 0);
+}
+
+// Slab form of fdtd_hip_two_steps (see fdtd_two_steps_impl) and of fdtd_hip_one_step: local arrays
+// that hold planes x_shift-4 .. of a domain of global_nx planes, global source positions.
+extern "C" int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m, const float *src,
+                                       const float *src_coords, const float *cur, const float *prev,
+                                       float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                                       int src_stride, int coord_stride, int variant, int flags, int x_shift,
+                                       int global_nx, float *scratch, long scratch_floats, void *stream) {
+  if (global_nx <= 0) return (int)hipErrorInvalidValue;
+  return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
+                             coord_stride, variant, flags, x_shift, global_nx, stream, nullptr, nullptr, scratch,
+                             scratch_floats);
+}
+
+extern "C" int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const float *src,
+                                      const float *src_coords, const float *cur, const float *prev, float *next,
+                                      int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                                      int variant, int x_shift, int global_nx, void *stream) {
+  if (!g || !m || !cur || !prev || !next || global_nx <= 0) return (int)hipErrorInvalidValue;
+  const bool has_src = p_src_M >= p_src_m;
+  if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
+  if (g->x_M < g->x_m) return 0;
+  const int rc = fdtd_stencil_levels(g, m, cur, prev, next, variant, stream);
+  if (rc || !has_src) return rc;
+  const int own_lo = (g->x_m + x_shift == 0 ? -1 : g->x_m + x_shift);
+  const int own_hi = (g->x_M + x_shift == global_nx - 1 ? global_nx : g->x_M + x_shift);
+  return fdtd_inject_level(g, m, src, src_coords, next, time, p_src_m, p_src_M, src_stride, coord_stride, x_shift,
+                           own_lo, own_hi, 0, 0, 0, stream);
 }
 
 // One step (sweep + scatter) on explicit level buffers: the single-step companion of
@@ -588,7 +670,7 @@ extern "C" int fdtd_hip_one_step(const struct fdtd_geom *g, const float *m, cons
   int rc = fdtd_stencil_levels(g, m, cur, prev, next, variant, stream);
   if (rc || !has_src) return rc;
   return fdtd_inject_level(g, m, src, src_coords, next, time, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                           g->x_m - 1, g->x_M + 1, 0, stream);
+                           g->x_m - 1, g->x_M + 1, 0, 0, 0, stream);
 }
 
 // Copies the shell (mode 1) or the shell and the box (mode 0) of one level into another.  A time

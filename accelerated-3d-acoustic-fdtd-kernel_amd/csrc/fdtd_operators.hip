@@ -135,7 +135,8 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
       const int rc = fdtd_two_steps_impl(g, m, has_src ? src : nullptr, has_src ? src_coords : nullptr, P[cur],
                                          P[prev], P[third], P[spare], time, has_src ? p_src_m : 0,
                                          has_src ? p_src_M : -1, src_stride, coord_stride, variant,
-                                         sources_inside ? 1 : 0, s, nullptr, timed ? pool.ev[nev + 1] : nullptr);
+                                         sources_inside ? 1 : 0, 0, 0, s, nullptr, timed ? pool.ev[nev + 1] : nullptr,
+                                         nullptr, 0);
       if (rc) return rc;
       const int ncur = spare, nprev = third, nthird = cur, nspare = prev;
       cur = ncur; prev = nprev; third = nthird; spare = nspare;
@@ -146,7 +147,7 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
       if (timed) FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev + 1], s));
       if (has_src) {
         rc = fdtd_inject_level(g, m, src, src_coords, P[third], time, p_src_m, p_src_M, src_stride, coord_stride, 0,
-                               g->x_m - 1, g->x_M + 1, 0, s);
+                               g->x_m - 1, g->x_M + 1, 0, 0, 0, s);
         if (rc) return rc;
       }
       const int ncur = third, nprev = cur, nthird = prev;

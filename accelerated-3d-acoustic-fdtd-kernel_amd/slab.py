@@ -200,6 +200,111 @@ class SlabPropagator:
                    stepper=stepper, comm=comm)
 
 
+PAIR_GHOST = 4  # planes handed over per side when two steps are taken per exchange
+
+
+class SlabPairPropagator:
+    """Time stepping of one slab, two steps per exchange (fdtd_hip_two_steps_slab).
+
+    `levels` are four tensors [nx_loc+8][nyp][nzp]: the three ring slots as they stand at `time0`
+    (slot i holds what level i of a [3][...] array holds) and one spare.  The 4-plane padding in
+    x is the ghost zone: a pair of steps reads u(t) four planes and u(t-1) two planes beyond the
+    owned range and recomputes u(t+1) on two ghost planes, bit for bit as the neighbour does.
+    After a pair the outermost 4 owned planes of u(t+2) and 2 of u(t+1) go to each neighbour; after
+    a single step (odd counts) the outermost 4 planes of the new level.  The schedule is the
+    two-chain one of SlabPropagator with a boundary zone of 4 planes.
+
+    In the reference's ring a level inherits the halo of the slot it overwrites (u(t+2) that of
+    u(t-1)); with four rotating buffers that is kept by copying the shell of `prev` into the
+    buffer that receives u(t+2) before every pair, unless `uniform_halos` promises that all slots
+    carry the same halo values and no source corner can land in the halo layer."""
+
+    def __init__(self, layout, rank, levels, m, src, coords, *, dt, h, o, stepper, comm, time0=0,
+                 uniform_halos=False):
+        self.layout, self.rank = layout, rank
+        self.levels, self.m = list(levels), m
+        self.nx = layout.nx_loc(rank)
+        self.x_off = layout.x_off(rank)
+        self.dt, self.h, self.o = dt, h, o
+        self.stepper, self.comm = stepper, comm
+        self.nsrc = 0 if src is None else int(src.shape[1])
+        self.src, self.coords = src, coords
+        self.uniform_halos = uniform_halos
+        if layout.world > 1 and min(layout.counts) < PAIR_GHOST:
+            raise ValueError("slabs thinner than 4 planes cannot take two steps per exchange")
+        self.cur, self.prev, self.third, self.spare = time0 % 3, (time0 + 2) % 3, (time0 + 1) % 3, 3
+        exchanging = layout.world > 1 or getattr(comm, "has_neighbours", False)
+        self.overlap = exchanging and self.nx >= 2 * PAIR_GHOST + 1 and stepper.pairs_can_overlap(self)
+        stepper.bind_pairs(self)
+
+    def _ranges(self):
+        nx, gw = self.nx, PAIR_GHOST
+        if self.overlap:
+            return [(gw, nx - gw - 1, False), (0, gw - 1, True), (nx - gw, nx - 1, True)]
+        return [(0, nx - 1, True)]
+
+    def pair(self, time):
+        """Steps `time` and `time + 1`."""
+        st = self.stepper
+        st.begin_step()
+        if not self.uniform_halos:
+            st.copy_shell(self.spare, self.prev)
+        for lo, hi, boundary in self._ranges():
+            st.two_steps(lo, hi, self.cur, self.prev, self.third, self.spare, time, boundary)
+            if not boundary:
+                st.interior_done()
+        st.boundary_done()
+        self.comm.exchange_planes(self, [(self.spare, PAIR_GHOST), (self.third, GHOST)])
+        self.cur, self.prev, self.third, self.spare = self.spare, self.third, self.cur, self.prev
+
+    def single(self, time):
+        """One step; the new level is handed over 4 planes deep so that a pair can follow."""
+        st = self.stepper
+        st.begin_step()
+        for lo, hi, boundary in self._ranges():
+            st.one_step(lo, hi, self.cur, self.prev, self.third, time, boundary)
+            if not boundary:
+                st.interior_done()
+        st.boundary_done()
+        self.comm.exchange_planes(self, [(self.third, PAIR_GHOST)])
+        self.cur, self.prev, self.third = self.third, self.cur, self.prev
+
+    def run(self, time_m, time_M):
+        time = time_m
+        while time + 1 <= time_M:
+            self.pair(time)
+            time += 2
+        if time <= time_M:
+            self.single(time)
+        self.stepper.finish()
+
+    def ring(self):
+        """The three newest levels in ring order: element i is what slot i of a [3][...] array holds
+        after the last step (roles: cur = u(T+1), prev = u(T), third = u(T-1))."""
+        return self.cur, self.prev, self.third
+
+    # planes of a level sent to / received from the neighbours (contiguous views)
+    def send_left(self, lvl, n=GHOST):
+        return self.levels[lvl][HALO:HALO + n]
+
+    def send_right(self, lvl, n=GHOST):
+        return self.levels[lvl][HALO + self.nx - n:HALO + self.nx]
+
+    def recv_left(self, lvl, n=GHOST):
+        return self.levels[lvl][HALO - n:HALO]
+
+    def recv_right(self, lvl, n=GHOST):
+        return self.levels[lvl][HALO + self.nx:HALO + self.nx + n]
+
+    def interior_cells(self):
+        nyp, nzp = self.levels[0].shape[1], self.levels[0].shape[2]
+        planes = self.nx - 2 * PAIR_GHOST if self.overlap else self.nx
+        return float(planes) * (nyp - 2 * HALO) * (nzp - 2 * HALO)
+
+    def mean_interior_kernel_ms(self):
+        return self.stepper.mean_interior_kernel_ms()
+
+
 def init_rccl(device, rank=None, world=None):
     """Process group for the ghost messages: backend "nccl" (= RCCL), communicator created eagerly
     on `device`.  RCCL's stream keeps the default priority: with a high-priority stream the
@@ -209,6 +314,30 @@ def init_rccl(device, rank=None, world=None):
     kw = {} if rank is None else {"rank": rank, "world_size": world}
     dist.init_process_group("nccl", device_id=device, **kw)
     return dist
+
+
+def standard_pair_benchmark(n_per_rank, ny, nz, nt, rank, world, device, variant=-1, global_x=0,
+                            self_exchange=False):
+    """The weak-scaling benchmark state of SlabPropagator.standard_benchmark for the two-steps-per-
+    exchange schedule: four zero level buffers, m = 1.5, one Ricker source inside the grid (zero
+    halos everywhere and no halo-layer corner: uniform_halos)."""
+    import torch
+    import torch.distributed as dist
+    NX = global_x if global_x else n_per_rank * world
+    layout = SlabLayout(NX, world)
+    nx = layout.nx_loc(rank)
+    shape = (nx + 2 * HALO, ny + 2 * HALO, nz + 2 * HALO)
+    levels = [torch.zeros(shape, dtype=torch.float32, device=device) for _ in range(4)]
+    m = torch.full(shape, 1.5, dtype=torch.float32, device=device)
+    src = torch.from_numpy(abi.fill_ricker(nt, 1)).to(device)
+    coords = torch.from_numpy(abi.fill_source_coords(1, NX, ny, nz)).to(device)
+    stepper = HipStepper(device, variant=variant, time_interior=True)
+    if self_exchange:
+        comm = TorchComm(dist, rank, world, stepper, left=rank, right=rank)
+    else:
+        comm = TorchComm(dist, rank, world, stepper)
+    return SlabPairPropagator(layout, rank, levels, m, src, coords, dt=1e-3, h=(0.1, 0.1, 0.1), o=(0.0, 0.0, 0.0),
+                              stepper=stepper, comm=comm, time0=0, uniform_halos=True)
 
 
 class HipStepper:
@@ -301,6 +430,97 @@ class HipStepper:
         if rc:
             raise RuntimeError(f"fdtd_hip_source_inject_slab failed with hipError {rc}")
 
+    # ---- two steps per exchange (SlabPairPropagator) ----
+    def pairs_can_overlap(self, prop):
+        """The boundary and interior calls may run side by side only when they are the fused sweep,
+        which stores nothing outside its range; the two-sweep fallback rewrites u(t+1) on two planes
+        of the neighbouring range, so it keeps to one chain."""
+        import os
+        if os.environ.get("FDTD_SLAB_OVERLAP", "1") == "0":
+            return False
+        nyp, nzp = prop.levels[0].shape[1:]
+        return (nzp - 2 * HALO == 512 and (nyp - 2 * HALO) % 8 == 0 and prop.nsrc <= 8
+                and os.environ.get("FDTD_FUSE2", "1") != "0" and self.variant in (-1, abi.VARIANTS["march2"]))
+
+    def bind_pairs(self, prop):
+        self.p = prop
+        nxp, nyp, nzp = prop.levels[0].shape
+        self.geom = abi.Geom(nxp, nyp, nzp, 0, prop.nx - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1,
+                             prop.dt, prop.h[0], prop.h[1], prop.h[2], prop.o[0], prop.o[1], prop.o[2])
+        self.lv_ptr = [t.data_ptr() for t in prop.levels]
+        self.m_ptr = prop.m.data_ptr()
+        self.src_ptr = prop.src.data_ptr() if prop.nsrc else None
+        self.coords_ptr = prop.coords.data_ptr() if prop.nsrc else None
+        self.src_stride = prop.src.shape[1] if prop.nsrc else 1
+        self.coord_stride = prop.coords.shape[1] if prop.nsrc else 3
+        if prop.overlap:
+            self.edge = self.torch.cuda.Stream(self.device)
+            self.edge.wait_stream(self.inner)
+        self.split = prop.overlap
+        self._sh = {True: C.c_void_p(self.edge.cuda_stream), False: C.c_void_p(self.inner.cuda_stream)}
+        self.flags = 1 if prop.uniform_halos else 0
+        # the boundary zones are updated next to the interior: their u(t+1) planes are built in scratch
+        self.scratch = None
+        if prop.overlap:
+            self.scratch = self.torch.empty((PAIR_GHOST + 4, nyp, nzp), dtype=self.torch.float32, device=self.device)
+
+    def _range_geom(self, x_lo, x_hi):
+        g = self._geoms.get((x_lo, x_hi))
+        if g is None:
+            g = abi.Geom.from_buffer_copy(self.geom)
+            g.x_m, g.x_M = x_lo, x_hi
+            self._geoms[(x_lo, x_hi)] = g
+        return g
+
+    def _timed(self, boundary, stream):
+        timed = self.time_interior and (not boundary or not self.split)
+        if timed:
+            self._launches += 1
+            timed = self._launches % self.TIMING_STRIDE == 0
+        if not timed:
+            return None
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        return e0, e1
+
+    def two_steps(self, x_lo, x_hi, cur, prev, n1, n2, time, boundary):
+        if x_hi < x_lo:
+            return
+        p, stream = self.p, (self.edge if boundary else self.inner)
+        ev = self._timed(boundary, stream)
+        # Side by side with the boundary zones the interior has to be the fused sweep whatever its
+        # length (it stores nothing outside its range); the zones themselves go through scratch.
+        variant = abi.VARIANTS["march2"] if (self.split and not boundary) else self.variant
+        rc = self.lib.fdtd_hip_two_steps_slab(
+            C.byref(self._range_geom(x_lo, x_hi)), self.m_ptr, self.src_ptr, self.coords_ptr, self.lv_ptr[cur],
+            self.lv_ptr[prev], self.lv_ptr[n1], self.lv_ptr[n2], time, 0, p.nsrc - 1, self.src_stride,
+            self.coord_stride, variant, self.flags, p.x_off, p.layout.NX,
+            self.scratch.data_ptr() if (boundary and self.scratch is not None) else None,
+            self.scratch.numel() if (boundary and self.scratch is not None) else 0, self._sh[boundary])
+        if rc:
+            raise RuntimeError(f"fdtd_hip_two_steps_slab failed with hipError {rc}")
+        if ev:
+            ev[1].record(stream)
+            self.timing.append(ev)
+
+    def one_step(self, x_lo, x_hi, cur, prev, nxt, time, boundary):
+        if x_hi < x_lo:
+            return
+        p = self.p
+        variant = -1 if self.variant == abi.VARIANTS["march2"] else self.variant
+        rc = self.lib.fdtd_hip_one_step_slab(
+            C.byref(self._range_geom(x_lo, x_hi)), self.m_ptr, self.src_ptr, self.coords_ptr, self.lv_ptr[cur],
+            self.lv_ptr[prev], self.lv_ptr[nxt], time, 0, p.nsrc - 1, self.src_stride, self.coord_stride,
+            variant, p.x_off, p.layout.NX, self._sh[boundary])
+        if rc:
+            raise RuntimeError(f"fdtd_hip_one_step_slab failed with hipError {rc}")
+
+    def copy_shell(self, dst, src):
+        # in the boundary chain: its event orders the copy before the next pair's interior reads
+        rc = self.lib.fdtd_hip_copy_shell(C.byref(self.geom), self.lv_ptr[dst], self.lv_ptr[src], 0, self._sh[True])
+        if rc:
+            raise RuntimeError(f"fdtd_hip_copy_shell failed with hipError {rc}")
+
     def boundary_done(self):
         if self.split:
             self.ev_boundary = self.torch.cuda.Event()
@@ -345,6 +565,47 @@ class TorchComm:
         self.has_neighbours = self.left is not None or self.right is not None
         self.backend = dist.get_backend() if self.has_neighbours else None
         self._ops = {}
+
+    def exchange_planes(self, prop, items):
+        """items: [(level index, planes per side), ...] — every listed block goes to both neighbours,
+        in list order (both sides list the same order, which is what matches sends to receives)."""
+        if not self.has_neighbours:
+            return
+        dist, st = self.dist, self.stepper
+        on_gpu = prop.levels[0].is_cuda
+        if on_gpu and self.backend == "nccl":
+            key = tuple(items)
+            ops = self._ops.get(key)
+            if ops is None:
+                ops = []
+                for peer, snd, rcv in ((self.left, prop.send_left, prop.recv_left),
+                                       (self.right, prop.send_right, prop.recv_right)):
+                    if peer is None:
+                        continue
+                    for lvl, n in items:
+                        ops.append(dist.P2POp(dist.isend, snd(lvl, n), peer))
+                        ops.append(dist.P2POp(dist.irecv, rcv(lvl, n), peer))
+                self._ops[key] = ops
+            with st.torch.cuda.stream(st.edge):
+                st.pending = list(dist.batch_isend_irecv(ops))
+            return
+        if on_gpu:
+            st.torch.cuda.synchronize(st.device)
+        stage = (lambda t: t.cpu().contiguous()) if on_gpu else (lambda t: t.contiguous())
+        reqs, recvs = [], []
+        for peer, snd, rcv in ((self.left, prop.send_left, prop.recv_left),
+                               (self.right, prop.send_right, prop.recv_right)):
+            if peer is None:
+                continue
+            for k, (lvl, n) in enumerate(items):
+                reqs.append(dist.isend(stage(snd(lvl, n)), peer, tag=k))
+                buf = stage(rcv(lvl, n))
+                reqs.append(dist.irecv(buf, peer, tag=k))
+                recvs.append((rcv(lvl, n), buf))
+        for q in reqs:
+            q.wait()
+        for dst, buf in recvs:
+            dst.copy_(buf)
 
     def exchange(self, prop, lvl):
         if not self.has_neighbours:

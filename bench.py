@@ -117,18 +117,31 @@ def main():
         else:
             dist.init_process_group(backend)
         slab = pkg.slab
-        prop = slab.SlabPropagator.standard_benchmark(n_per_rank=n, ny=n, nz=n, nt=total_steps,
-                                                     rank=rank, world=world, device=dev,
-                                                     variant=variant, global_x=args.global_x,
-                                                     self_exchange=args.self_exchange and world == 1)
-        for t in range(W):
-            prop.step(t)
+        # two steps per exchange (fused sweep, 4-plane ghosts) where the slab's cross-section allows it
+        pairs = (args.variant in ("auto", "march2") and os.environ.get("FDTD_FUSE2", "1") != "0"
+                 and n == 512 and args.storage == "f32")
+        maker = slab.standard_pair_benchmark if pairs else slab.SlabPropagator.standard_benchmark
+        prop = maker(n_per_rank=n, ny=n, nz=n, nt=total_steps + 1, rank=rank, world=world, device=dev,
+                     variant=variant, global_x=args.global_x, self_exchange=args.self_exchange and world == 1)
+
+        def advance(t_from, t_to):
+            t = t_from
+            if pairs:
+                while t + 1 < t_to:
+                    prop.pair(t)
+                    t += 2
+                if t < t_to:
+                    prop.single(t)
+            else:
+                for t in range(t_from, t_to):
+                    prop.step(t)
+
+        advance(0, W)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        for t in range(W, total_steps):
-            prop.step(t)
+        advance(W, total_steps)
         t_issue = time.perf_counter() - t_start
         prop.stepper.finish()       # the last step's ghosts have arrived
         t_fin = time.perf_counter() - t_start
@@ -143,7 +156,8 @@ def main():
         elapsed = float(tmax.item())
         kernel_ms = prop.mean_interior_kernel_ms()
         cells_per_step = float(prop.layout.NX) * n * n
-        launch_cells = prop.interior_cells()
+        updates_per_launch = 2 if pairs else 1
+        launch_cells = prop.interior_cells() * updates_per_launch
         dist.destroy_process_group()
     else:
         u, m, src, coords = pkg.standard_inputs(n, n, n, total_steps, 1)
@@ -264,15 +278,17 @@ def main():
         "config": {
             "workload": (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
                          f"{total_steps} steps ({W} untimed)" if not slabs else
-                         f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, 2-plane ghost exchange "
-                         f"per step over RCCL, {total_steps} steps ({W} untimed)"),
+                         f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, "
+                         + ("two steps per sweep and exchange (4 + 2 ghost planes per side)" if updates_per_launch == 2
+                            else "2-plane ghost exchange per step")
+                         + f" over RCCL, {total_steps} steps ({W} untimed)"),
             "variant": args.variant,
             "bytes_per_cell_update": ALGO_BYTES_PER_CELL,
         },
         "roofline": {
             "bound": "hbm",
             "kernel": ("stencil_march2_kernel: two-step sweep, two cell updates and both source scatters per launch"
-                       if (not slabs and updates_per_launch == 2) else "stencil sweep (section0)"),
+                       if updates_per_launch == 2 else "stencil sweep (section0)"),
             "cell_updates_per_launch": launch_cells,
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,

@@ -182,6 +182,32 @@ int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float
                           int src_stride, int coord_stride, int variant, int flags,
                           void *ev_begin, void *ev_end, void *stream);
 
+/* Slab forms for domains cut along x (one slab per GPU; no counterpart in the reference, which
+ * is single-device).  The level buffers and m are local arrays of (nx_loc+8) planes holding
+ * planes x_shift-4 .. x_shift+nx_loc+3 of a domain of global_nx planes; g->x_m..x_M is the local
+ * range to update (a subset of 0..nx_loc-1); source positions are global.  Halo-layer corners
+ * are applied by the call whose range contains their plane (the first / last plane of the
+ * domain also owns the plane beyond it).
+ * two_steps: cur must be valid 4 planes and prev 2 planes beyond the range on either side
+ * (ghost planes received from the neighbours, or the physical halo); u(time+1) is computed
+ * two planes beyond the range as well, bit for bit as the owner of those planes computes it.
+ * The fused sweep keeps those extra planes in registers.  Ranges it does not take (fewer than
+ * 32 planes, other shapes) are run as two sweeps; with a `scratch` of at least
+ * (x_M - x_m + 5) planes (nyp*nzp floats each) those build the extra planes there and store
+ * nothing outside the range, which is what a range needs that is updated while its
+ * neighbouring ranges are (the boundary zone of a slab); without scratch (NULL) the first of
+ * the two sweeps stores u(time+1) on the extra planes of next1 too (same values as their owner
+ * stores), so such calls must not run concurrently with calls on adjacent ranges. */
+int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m, const float *src,
+                            const float *src_coords, const float *cur, const float *prev,
+                            float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                            int src_stride, int coord_stride, int variant, int flags, int x_shift,
+                            int global_nx, float *scratch, long scratch_floats, void *stream);
+int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const float *src,
+                           const float *src_coords, const float *cur, const float *prev, float *next,
+                           int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
+                           int variant, int x_shift, int global_nx, void *stream);
+
 /* One step (sweep of openacc.cpp:151-168 + scatter of openacc.cpp:173-203) on three separate
  * level buffers: next = u(time+1) from cur = u(time) and prev = u(time-1). */
 int fdtd_hip_one_step(const struct fdtd_geom *g, const float *m, const float *src,

@@ -83,10 +83,13 @@ static void oracle_section1(const float *restrict m, const float *restrict src,
                             int z_m, int z_M, float h_x, float h_y, float h_z,
                             float o_x, float o_y, float o_z, int p_src_m,
                             int p_src_M, int time, long src_stride,
-                            long coord_stride, int x_shift, int x_lo, int x_hi) {
+                            long coord_stride, int x_shift, int x_lo, int x_hi, int mode,
+                            int gx_m, int gx_M) {
   /* x_shift/x_lo/x_hi: slab form used by the decomposition tests (arrays hold global planes
    * x_shift-4.., a corner is applied iff its global x lies in [x_lo, x_hi]); the reference
-   * itself is the case x_shift = 0, x_lo = x_m-1, x_hi = x_M+1. */
+   * itself is the case x_shift = 0, x_lo = x_m-1, x_hi = x_M+1.  mode 1 / 2 keep only the corners
+   * that land outside / inside the box [gx_m,gx_M] x [y_m,y_M] x [z_m,z_M] (tests of the
+   * two-steps-per-call schedule, which treats the two kinds at different moments); 0 keeps all. */
   const long sx = nyp * nzp, sy = nzp;
   for (int p = p_src_m; p <= p_src_M; p += 1) {
     for (int rx = 0; rx <= 1; rx += 1) {
@@ -105,6 +108,9 @@ static void oracle_section1(const float *restrict m, const float *restrict src,
           (void)x_M;
           if (rx + posx >= x_lo && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
               rx + posx <= x_hi && ry + posy <= y_M + 1 && rz + posz <= z_M + 1) {
+            const int inside = rx + posx >= gx_m && rx + posx <= gx_M && ry + posy >= y_m &&
+                               ry + posy <= y_M && rz + posz >= z_m && rz + posz <= z_M;
+            if ((mode == 1 && inside) || (mode == 2 && !inside)) continue;
             const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) *
                              (ry * py + (1 - ry) * (1 - py)) *
                              (rz * pz + (1 - rz) * (1 - pz)) *
@@ -149,7 +155,7 @@ int Oracle_Kernel_OpenACC(FDTD_OPERATOR_ARGS) {
     if (has_src)
       oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
                       z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time,
-                      src_stride, coord_stride, 0, x_m - 1, x_M + 1);
+                      src_stride, coord_stride, 0, x_m - 1, x_M + 1, 0, 0, 0);
     if (timed) {
       double c = now_s();
       timers->section0 += b - a;
@@ -183,7 +189,7 @@ void oracle_source_inject(const float *m, const float *src, const float *coords,
   const long vol = nxp * nyp * nzp;
   oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
                   z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time,
-                  src_stride, coord_stride, 0, x_m - 1, x_M + 1);
+                  src_stride, coord_stride, 0, x_m - 1, x_M + 1, 0, 0, 0);
 }
 
 void oracle_source_inject_slab(const float *m, const float *src, const float *coords,
@@ -195,7 +201,20 @@ void oracle_source_inject_slab(const float *m, const float *src, const float *co
   const long vol = nxp * nyp * nzp;
   oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, 0, 0, y_m, y_M, z_m, z_M, h_x,
                   h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time, src_stride, coord_stride,
-                  x_shift, x_lo, x_hi);
+                  x_shift, x_lo, x_hi, 0, 0, 0);
+}
+
+/* The slab scatter restricted to corners outside (mode 1) or inside (mode 2) the domain's box. */
+void oracle_source_inject_slab_mode(const float *m, const float *src, const float *coords,
+                                    float *u, long nxp, long nyp, long nzp, int y_m, int y_M,
+                                    int z_m, int z_M, float h_x, float h_y, float h_z, float o_x,
+                                    float o_y, float o_z, int p_src_m, int p_src_M, int time,
+                                    long src_stride, long coord_stride, int t2, int x_shift,
+                                    int x_lo, int x_hi, int mode, int gx_m, int gx_M) {
+  const long vol = nxp * nyp * nzp;
+  oracle_section1(m, src, coords, u + t2 * vol, nyp, nzp, 0, 0, y_m, y_M, z_m, z_M, h_x,
+                  h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time, src_stride, coord_stride,
+                  x_shift, x_lo, x_hi, mode, gx_m, gx_M);
 }
 
 /* main.cpp:573-593, the driver's parity metrics, restated independently of the

@@ -37,6 +37,8 @@ def oracle():
                                                 + [C.c_float] * 6 + [C.c_int] * 3 + [C.c_long] * 2
                                                 + [C.c_int] * 4)
         L.oracle_source_inject_slab.restype = None
+        L.oracle_source_inject_slab_mode.argtypes = L.oracle_source_inject_slab.argtypes + [C.c_int] * 3
+        L.oracle_source_inject_slab_mode.restype = None
         L.oracle_compare_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(pkg.Parity)]
         L.oracle_compare_fields.restype = None

@@ -63,9 +63,133 @@ class OracleStepper:
         pass
 
 
+class OraclePairStepper:
+    """CPU stand-in for the two-steps-per-exchange calls: what fdtd_hip_two_steps_slab and
+    fdtd_hip_one_step_slab are specified to do, with the oracle's sweeps on one [4][...] array."""
+
+    def __init__(self, U):
+        import oracle_binding as ob
+        self.ob, self.U = ob, U.numpy()
+
+    def pairs_can_overlap(self, prop):
+        return True          # sequential here, so the three ranges of the two-chain schedule are exercised
+
+    def bind_pairs(self, prop):
+        self.p = prop
+        self.m = prop.m.numpy()
+        self.src = prop.src.numpy() if prop.nsrc else None
+        self.coords = prop.coords.numpy() if prop.nsrc else None
+
+    def begin_step(self):
+        pass
+
+    def _stencil(self, lo, hi, t0, t1, t2):
+        nyp, nzp = self.U.shape[2:]
+        self.ob.oracle_stencil_step(self.m, self.U, (lo, hi, 0, nyp - 9, 0, nzp - 9), np.float32(self.p.dt),
+                                    tuple(np.float32(v) for v in self.p.h), t0, t1, t2)
+
+    def _inject(self, lvl, time, g_lo, g_hi, mode):
+        p = self.p
+        if not p.nsrc or g_hi < g_lo:
+            return
+        nxp, nyp, nzp = self.U.shape[1:]
+        self.ob.oracle().oracle_source_inject_slab_mode(
+            self.m.ctypes.data, self.src.ctypes.data, self.coords.ctypes.data, self.U.ctypes.data,
+            nxp, nyp, nzp, 0, nyp - 9, 0, nzp - 9, *[float(v) for v in p.h], *[float(v) for v in p.o],
+            0, p.nsrc - 1, time, self.src.shape[1], self.coords.shape[1], lvl, p.x_off, g_lo, g_hi, mode,
+            0, p.layout.NX - 1)
+
+    def _own(self, lo, hi):
+        p = self.p
+        g_lo, g_hi = lo + p.x_off, hi + p.x_off
+        return (-1 if g_lo == 0 else g_lo), (p.layout.NX if g_hi == p.layout.NX - 1 else g_hi)
+
+    def two_steps(self, lo, hi, cur, prev, n1, n2, time, boundary):
+        if hi < lo:
+            return
+        p = self.p
+        d_lo, d_hi = -p.x_off, p.layout.NX - 1 - p.x_off
+        e_lo, e_hi = max(lo - 2, d_lo), min(hi + 2, d_hi)
+        own = self._own(lo, hi)
+        self._inject(n1, time, *own, 1)
+        self._inject(n2, time + 1, *own, 1)
+        self._stencil(e_lo, e_hi, cur, prev, n1)
+        self._inject(n1, time, e_lo + p.x_off, e_hi + p.x_off, 2)
+        self._stencil(lo, hi, n1, cur, n2)
+        self._inject(n2, time + 1, lo + p.x_off, hi + p.x_off, 2)
+
+    def one_step(self, lo, hi, cur, prev, nxt, time, boundary):
+        if hi < lo:
+            return
+        self._stencil(lo, hi, cur, prev, nxt)
+        self._inject(nxt, time, *self._own(lo, hi), 0)
+
+    def copy_shell(self, dst, src):
+        nx = self.p.nx
+        a, b = self.U[dst], self.U[src]
+        box = (slice(HALO, HALO + nx), slice(HALO, -HALO), slice(HALO, -HALO))
+        grown = (slice(HALO - 2, HALO + nx + 2), slice(HALO - 2, -HALO + 2), slice(HALO - 2, -HALO + 2))
+        keep = a[box].copy()
+        a[grown] = b[grown]
+        a[box] = keep
+
+    def interior_done(self):
+        pass
+
+    def boundary_done(self):
+        pass
+
+    def finish(self):
+        pass
+
+
+def pair_run(kind, name, outdir):
+    """One rank of a two-steps-per-exchange run (kind: oracle_pair over gloo on the CPU, hip_pair
+    with the HIP kernels, ghosts staged through the host)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_package()
+    c = cases.build(name, pkg)
+    kw = c["kw"]
+    h, dt = kw.get("h", (0.1, 0.1, 0.1)), kw.get("dt", 1e-3)
+    NX = c["u"].shape[1] - 2 * HALO
+    layout = pkg.slab.SlabLayout(NX, world)
+    time_m = kw.get("time_m", 0)
+    time_M = kw.get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
+    u_loc = layout.cut(c["u"], rank, axis=1)
+    U = torch.zeros((4,) + u_loc.shape[1:], dtype=torch.float32)
+    U[:3] = torch.from_numpy(np.ascontiguousarray(u_loc))
+    m_loc = torch.from_numpy(np.ascontiguousarray(layout.cut(c["m"], rank, axis=0)))
+    dev = "cpu" if kind == "oracle_pair" else torch.device("cuda", 0)
+    U, m_loc = U.to(dev), m_loc.to(dev)
+    src_t = None if c["src"] is None else torch.from_numpy(c["src"]).to(dev)
+    coords_t = None if c["coords"] is None else torch.from_numpy(c["coords"]).to(dev)
+    stepper = OraclePairStepper(U) if kind == "oracle_pair" else pkg.slab.HipStepper(dev, variant=pkg.VARIANTS["auto"])
+    comm = pkg.slab.TorchComm(dist, rank, world, stepper)
+    prop = pkg.slab.SlabPairPropagator(layout, rank, [U[i] for i in range(4)], m_loc, src_t, coords_t, dt=dt, h=h,
+                                       o=(0.0, 0.0, 0.0), stepper=stepper, comm=comm, time0=time_m)
+    prop.run(time_m, time_M)
+    # back into ring order; the shell travels with the level, padding further out stays with the slot
+    out = torch.from_numpy(np.ascontiguousarray(u_loc)).clone()
+    Uc = U.cpu()
+    T = time_M
+    nx = prop.nx
+    grown = (slice(HALO - 2, HALO + nx + 2), slice(HALO - 2, -HALO + 2), slice(HALO - 2, -HALO + 2))
+    for role, slot in zip(prop.ring(), ((T + 1) % 3, T % 3, (T + 2) % 3)):
+        out[slot][grown] = Uc[role][grown]
+    np.save(os.path.join(outdir, f"u_rank{rank}.npy"), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 class SelfCopyComm:
     """What a rank that is its own left and right neighbour receives: its own boundary planes."""
     has_neighbours = True
+
+    def exchange_planes(self, prop, items):
+        for lvl, n in items:
+            prop.recv_left(lvl, n).copy_(prop.send_left(lvl, n).clone())
+            prop.recv_right(lvl, n).copy_(prop.send_right(lvl, n).clone())
 
     def exchange(self, prop, lvl):
         prop.recv_left(lvl).copy_(prop.send_left(lvl).clone())
@@ -113,10 +237,53 @@ def self_neighbour_run(name, outdir):
     sys.exit(0 if nbad == 0 and ghosts_used else 1)
 
 
+def self_neighbour_pair_run(name, outdir):
+    """The two-steps-per-exchange schedule with real RCCL messages on one GPU (the rank is its own
+    two neighbours), against the same orchestration on the CPU."""
+    pkg = load_package()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    pkg.slab.init_rccl(dev, 0, 1)
+    c = cases.build(name, pkg)
+    kw = c["kw"]
+    h, dt = kw.get("h", (0.1, 0.1, 0.1)), kw.get("dt", 1e-3)
+    NX = c["u"].shape[1] - 2 * HALO
+    time_m = kw.get("time_m", 0)
+    time_M = kw.get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
+    layout = pkg.slab.SlabLayout(NX, 1)
+    results = []
+    for kind in ("oracle", "hip"):
+        d = "cpu" if kind == "oracle" else dev
+        U = torch.zeros((4,) + c["u"].shape[1:], dtype=torch.float32)
+        U[:3] = torch.from_numpy(c["u"])
+        U, m_t = U.to(d), torch.from_numpy(c["m"]).to(d)
+        src_t = None if c["src"] is None else torch.from_numpy(c["src"]).to(d)
+        coords_t = None if c["coords"] is None else torch.from_numpy(c["coords"]).to(d)
+        if kind == "oracle":
+            stepper, comm = OraclePairStepper(U), SelfCopyComm()
+        else:
+            stepper = pkg.slab.HipStepper(dev, variant=pkg.VARIANTS["auto"])
+            comm = pkg.slab.TorchComm(dist, 0, 1, stepper, left=0, right=0)
+        prop = pkg.slab.SlabPairPropagator(layout, 0, [U[i] for i in range(4)], m_t, src_t, coords_t, dt=dt, h=h,
+                                           o=(0.0, 0.0, 0.0), stepper=stepper, comm=comm, time0=time_m)
+        assert prop.overlap
+        prop.run(time_m, time_M)
+        results.append(torch.stack([U[i] for i in prop.ring()]).cpu().numpy())
+    dist.destroy_process_group()
+    a, b = (r.view(np.uint32) for r in results)
+    nbad = int((a != b).sum())
+    print(f"self-neighbour nccl pair run: {nbad} differing words")
+    sys.exit(0 if nbad == 0 else 1)
+
+
 def main():
     kind, name, outdir = sys.argv[1:4]
+    if kind == "nccl_self_pair":
+        return self_neighbour_pair_run(name, outdir)
     if kind == "nccl_self":
         return self_neighbour_run(name, outdir)
+    if kind in ("oracle_pair", "hip_pair"):
+        return pair_run(kind, name, outdir)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = load_package()

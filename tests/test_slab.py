@@ -67,6 +67,26 @@ def test_slab_orchestration_cpu(pkg, tmp_path, name, world):
     check_against_golden(name, u, exact=True)
 
 
+# Two steps per exchange: 4-plane ghosts, u(t+1) recomputed on two ghost planes, shells following the ring.
+# noncubic_aniso has a source in the outermost cell (halo-layer corners), time_offset an odd start and
+# an odd number of steps (pairs, then one single step), ricker27 sources on and next to the cuts.
+@pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("ricker27_n32", 3), ("noncubic_aniso", 2),
+                                        ("time_offset", 2), ("odd_sizes", 2), ("no_sources_random", 3)])
+def test_slab_pairs_orchestration_cpu(pkg, tmp_path, name, world):
+    u = run_slabs("oracle_pair", name, world, tmp_path, pkg)
+    check_against_golden(name, u, exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("fused_z512", 2), ("fused_z512_edge_source", 2), ("fused_z512_ricker8", 3),
+                                        ("ricker27_n32", 2)])
+def test_slab_pairs_hip_ranks_one_gpu(pkg, tmp_path, name, world):
+    """The fused sweep inside the slab schedule (512-wide cases: boundary and interior calls on two
+    streams) and the two-sweep fallback (32^3), ranks sharing one GPU."""
+    u = run_slabs("hip_pair", name, world, tmp_path, pkg)
+    check_against_golden(name, u, exact=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("noncubic_aniso", 2), ("time_offset", 3),
                                         ("ricker30_n24_overlap", 2)])
@@ -85,5 +105,17 @@ def test_slab_rccl_schedule_one_gpu(pkg, tmp_path, name, march):
     if march:   # the marching kernel also on these small grids
         env.update(FDTD_MARCH_MIN_CELLS="0", FDTD_MARCH_MIN_PLANES="1")
     p = subprocess.run([sys.executable, os.path.join(HERE, "slab_worker.py"), "nccl_self", name, str(tmp_path)],
+                       env=env, timeout=300)
+    assert p.returncode == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fused_z512", "fused_z512_edge_source", "fused_z512_ricker8"])
+def test_slab_pairs_rccl_schedule_one_gpu(pkg, tmp_path, name):
+    """Two steps per exchange with real RCCL messages (4 + 2 planes per side and pair) next to the fused
+    interior sweep, one rank as its own two neighbours; bit-identical to the CPU orchestration."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "slab_worker.py"), "nccl_self_pair", name, str(tmp_path)],
                        env=env, timeout=300)
     assert p.returncode == 0
