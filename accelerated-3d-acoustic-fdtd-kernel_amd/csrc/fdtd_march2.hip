@@ -151,19 +151,17 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int yhalo = q < 2 ? yb - 4 + q : yb + 8 + q;   // B row outside the 12-row stack
   const int hslot = q < 2 ? q : 12 + q;
   const int lz = h * 64 + lane;                         // float4 index inside the 512-cell row
-  const unsigned zc = (unsigned)(a.z_m + lz * 4 + FDTD_HALO);
-  unsigned voff[3], veoff[3], vceoff[2];
+  // Addresses: descriptor base + scalar offset (plane + row, wave-uniform) + one lane offset along z.
+  // vz: the lane's 4 cells; vze: the 2 cells before them, or behind them in the last lane; vzc: the
+  // same for the C array, where only the two cells before lane 0 / behind lane 63 are ever used, so
+  // the lanes in between repeat lane 0's address instead of touching the whole row.
+  const unsigned vz = (unsigned)(a.z_m + lz * 4 + FDTD_HALO) * 4u;
+  const unsigned vze = lane == 63 ? vz + 16u : vz - 8u;
+  const unsigned vzc = lane == 63 ? vz + 16u : vz - (unsigned)lane * 16u - 8u;
+  int rowoff[3];   // byte offset of the segment's row inside a plane
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    // byte offsets inside a plane
-    voff[s] = ((unsigned)(yrow[s] + FDTD_HALO) * (unsigned)a.sy + zc) * 4u;
-    veoff[s] = lane == 63 ? voff[s] + 16u : voff[s] - 8u;   // cells (z+4, z+5) or (z-2, z-1)
-  }
-  // C array edges: only the two cells before lane 0 / behind lane 63 are ever used; the lanes in
-  // between repeat lane 0's address instead of touching the whole row
-#pragma unroll
-  for (int s = 0; s < 2; ++s) vceoff[s] = lane == 63 ? voff[s] + 16u : voff[s] - (unsigned)lane * 16u - 8u;
-  const unsigned vhoff = ((unsigned)(yhalo + FDTD_HALO) * (unsigned)a.sy + zc) * 4u;
+  for (int s = 0; s < 3; ++s) rowoff[s] = (yrow[s] + FDTD_HALO) * a.sy * 4;
+  const int rowoff_h = (yhalo + FDTD_HALO) * a.sy * 4;
   const int sxb = (int)(a.sx * 4);   // bytes per plane
 
   // descriptors are based at the lowest plane this workgroup touches, so that plane offsets stay
@@ -236,10 +234,10 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, sp + (i - 2) * sxb, voff[s]);
-    av[s] = s == 0 ? LD4S(rA, sp, voff[s]) : LD4(rA, sp, voff[s]);
-    mv[s] = s == 0 ? LD4S(rM, sp, voff[s]) : LD4(rM, sp, voff[s]);
-    be[s] = LD2(rB, sp, veoff[s]);
+    for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, (sp + (i - 2) * sxb) + rowoff[s], vz);
+    av[s] = s == 0 ? LD4S(rA, (sp) + rowoff[s], vz) : LD4(rA, (sp) + rowoff[s], vz);
+    mv[s] = s == 0 ? LD4S(rM, (sp) + rowoff[s], vz) : LD4(rM, (sp) + rowoff[s], vz);
+    be[s] = LD2(rB, (sp) + rowoff[s], vze);
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -248,14 +246,14 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     mh[0][s] = mh[1][s] = f32x4{1, 1, 1, 1};
     ce[s] = f32x2{0, 0};
   }
-  bh = LD4(rB, sp + sxb, vhoff);
-  bh2 = LD4(rB, sp + 2 * sxb, vhoff);
-  ch = seg2_outside ? LD4(rC, sp, voff[2]) : f32x4{0, 0, 0, 0};
+  bh = LD4(rB, (sp + sxb) + rowoff_h, vz);
+  bh2 = LD4(rB, (sp + 2 * sxb) + rowoff_h, vz);
+  ch = seg2_outside ? LD4(rC, (sp) + rowoff[2], vz) : f32x4{0, 0, 0, 0};
   {  // B(p0): own rows and the outside row
     const int buf = p0 & 1;
 #pragma unroll
     for (int s = 0; s < 3; ++s) Bbuf[buf][cslot[s] + 2][lz] = bc[2][s];
-    Bbuf[buf][hslot][lz] = LD4(rB, sp, vhoff);
+    Bbuf[buf][hslot][lz] = LD4(rB, (sp) + rowoff_h, vz);
   }
   __syncthreads();
   int ring_w = ((p0 % 3) + 3) % 3;        // ring slot written this iteration (plane p)
@@ -292,10 +290,10 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
         if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
       } else {   // halo plane of the domain: the intermediate level keeps what memory holds there
-        cnew = LD4(rC, sp, voff[s]);
+        cnew = LD4(rC, (sp) + rowoff[s], vz);
       }
       if constexpr (s < 2) {
-        if (store_c) st4<NT>(rC, sp, voff[s], cnew);
+        if (store_c) st4<NT>(rC, (sp) + rowoff[s], vz, cnew);
       }
       Cring[ring_w][r][lz] = cnew;
       // ---- D(p-2) ----
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
           f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
                                PB(0)[s], mh[0][s]);
           if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
-          st4<NT>(rD, sp - 2 * sxb, voff[s], o);
+          st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vz, o);
         }
         if (STEADY) {
           PC(4)[s] = cnew;
@@ -327,21 +325,21 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     auto reload = [&](auto seg) __attribute__((always_inline)) {
       constexpr int s = decltype(seg)::value;
       const int r = cslot[s];
-      if constexpr (s < 2) ce[s] = LD2(rC, sq - 2 * sxb, vceoff[s]);   // C array, plane (p+1)-2
+      if constexpr (s < 2) ce[s] = LD2(rC, (sq - 2 * sxb) + rowoff[s], vzc);   // C array, plane (p+1)-2
       if (STEADY) {
         Bbuf[buf ^ 1][r + 2][lz] = PB(3)[s];           // B(p+1), centre plane of the next iteration
-        PB(0)[s] = LD4(rB, sq + 2 * sxb, voff[s]);     // B(p+3) replaces B(p-2)
+        PB(0)[s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);     // B(p+3) replaces B(p-2)
       } else {
         bc[0][s] = bc[1][s];
         bc[1][s] = bc[2][s];
         bc[2][s] = bc[3][s];
         bc[3][s] = bc[4][s];
         Bbuf[buf ^ 1][r + 2][lz] = bc[2][s];
-        bc[4][s] = LD4(rB, sq + 2 * sxb, voff[s]);
+        bc[4][s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);
       }
-      av[s] = s == 0 ? LD4S(rA, sq, voff[s]) : LD4(rA, sq, voff[s]);
-      mv[s] = s == 0 ? LD4S(rM, sq, voff[s]) : LD4(rM, sq, voff[s]);
-      be[s] = LD2(rB, sq, veoff[s]);
+      av[s] = s == 0 ? LD4S(rA, (sq) + rowoff[s], vz) : LD4(rA, (sq) + rowoff[s], vz);
+      mv[s] = s == 0 ? LD4S(rM, (sq) + rowoff[s], vz) : LD4(rM, (sq) + rowoff[s], vz);
+      be[s] = LD2(rB, (sq) + rowoff[s], vze);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -357,8 +355,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     reload(S0{});
     Bbuf[buf ^ 1][hslot][lz] = bh;
     bh = bh2;
-    bh2 = LD4(rB, sq + 2 * sxb, vhoff);
-    if (seg2_outside) ch = LD4(rC, sq, voff[2]);
+    bh2 = LD4(rB, (sq + 2 * sxb) + rowoff_h, vz);
+    if (seg2_outside) ch = LD4(rC, (sq) + rowoff[2], vz);
     __syncthreads();
     ring_w = ring_w == 2 ? 0 : ring_w + 1;
     ring_r = ring_r == 2 ? 0 : ring_r + 1;
