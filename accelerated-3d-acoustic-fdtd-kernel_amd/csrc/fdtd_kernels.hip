@@ -931,8 +931,12 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
   a.src_stride = src_stride; a.coord_stride = coord_stride;
   a.x_shift = x_shift; a.x_lo = x_lo; a.x_hi = x_hi;
   const long threads = (long)(p_src_M - p_src_m + 1) * 8;
-  if (threads <= 1024 && env_int("FDTD_INJECT_ATOMIC", 0) == 0)
-    hipLaunchKernelGGL(source_inject_ordered_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  if (threads <= 1024 && env_int("FDTD_INJECT_ATOMIC", 0) == 0) {
+    // one workgroup of just enough waves: a small workgroup still finds room on a CU that a
+    // register-heavy sweep occupies, a 1024-thread one waits until the sweep drains
+    const unsigned block = (unsigned)((threads + 63) / 64 * 64);
+    hipLaunchKernelGGL(source_inject_ordered_kernel, dim3(1), dim3(block), 0, (hipStream_t)stream, a);
+  }
   else
     hipLaunchKernelGGL(source_inject_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, a);

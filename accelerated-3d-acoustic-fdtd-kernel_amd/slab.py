@@ -366,6 +366,12 @@ class HipStepper:
         self.ev_boundary = None     # last recorded boundary / interior events
         self.ev_interior = None
         self.pending = []           # message requests the next boundary update waits for
+        # Two steps per exchange only: the interior sweep also waits for the previous messages.  It
+        # does not need them, but RCCL's waves do not fit next to the fused sweep's (136 + 2 x 216
+        # registers per SIMD lane), so messages issued while a sweep runs complete when it drains; if
+        # the next sweep started before that, the boundary zone would fall a whole sweep behind and
+        # stay there (its result is what the sweep after needs).
+        self.hold_interior = False
         self.time_interior = time_interior
         self.timing = []
         self._launches = 0
@@ -396,6 +402,10 @@ class HipStepper:
             with self.torch.cuda.stream(self.edge):
                 for req in self.pending:
                     req.wait()          # stream-side wait; the host does not block
+            if self.split and self.hold_interior:
+                with self.torch.cuda.stream(self.inner):
+                    for req in self.pending:
+                        req.wait()
             self.pending = []
 
     def stencil(self, x_lo, x_hi, t0, t1, t2, boundary):
@@ -459,6 +469,7 @@ class HipStepper:
         self.split = prop.overlap
         self._sh = {True: C.c_void_p(self.edge.cuda_stream), False: C.c_void_p(self.inner.cuda_stream)}
         self.flags = 1 if prop.uniform_halos else 0
+        self.hold_interior = True
         # the boundary zones are updated next to the interior: their u(t+1) planes are built in scratch
         self.scratch = None
         if prop.overlap:
