@@ -430,6 +430,8 @@ int launch_shell(const struct fdtd_geom *g, float *dst, const float *a, const fl
   return (int)hipGetLastError();
 }
 
+long g_fused_launches = 0;   // statistics: launches of the two-step sweep in this process
+
 int env_int2(const char *name, int fallback) {
   const char *v = getenv(name);
   return v ? atoi(v) : fallback;
@@ -602,6 +604,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       hipLaunchKernelGGL((stencil_march2_kernel<true>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
     else
       hipLaunchKernelGGL((stencil_march2_kernel<false>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
+    __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
   }
   const int rc = (int)hipGetLastError();
   if (rc) return rc;
@@ -655,6 +658,10 @@ extern "C" int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m,
   return fdtd_inject_level(g, m, src, src_coords, next, time, p_src_m, p_src_M, src_stride, coord_stride, x_shift,
                            own_lo, own_hi, 0, 0, 0, stream);
 }
+
+// Number of two-step sweep launches issued by this process so far (lets a caller or a test see
+// whether a run took the fused path or the two-sweep one).
+extern "C" long fdtd_hip_fused_launch_count(void) { return __atomic_load_n(&g_fused_launches, __ATOMIC_RELAXED); }
 
 // One step (sweep + scatter) on explicit level buffers: the single-step companion of
 // fdtd_hip_two_steps for callers that rotate four buffers.

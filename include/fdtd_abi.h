@@ -171,6 +171,10 @@ int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *s
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,
                        int src_stride, int coord_stride, int variant, void *stream);
 
+/* Statistics: how many two-step sweep kernels this process has launched so far (tells a
+ * caller whether its calls were fused or ran as two sweeps). */
+long fdtd_hip_fused_launch_count(void);
+
 /* The same with two extras for callers that measure or know more: ev_begin / ev_end
  * (hipEvent_t, may be NULL) are recorded right before the first and right after the last
  * sweep kernel; flags bit 0 (FDTD_TWO_STEPS_SOURCES_INSIDE) promises that no source corner

@@ -53,6 +53,9 @@ CASES = {
     "fused_z512_edge_source": ("random", dict(n=(36, 24, 512), nt=17, nsrc=2, h=(0.8, 1.0, 1.25), seed=23,
                                               edge_source=True, time_m=7)),
     "fused_z512_ricker8": ("ricker", dict(n=(34, 16, 512), nt=14, nsrc=8)),
+    # the fused sweep on a box strictly inside the arrays: x 2..37, y 8..23, z 4..515 of 40 x 32 x 520
+    "fused_z512_subrange": ("random", dict(n=(40, 32, 520), nt=9, nsrc=2, h=(1.0, 1.0, 1.0), seed=24,
+                                           bounds=(2, 37, 8, 23, 4, 515))),
     "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
     "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
 }

@@ -26,8 +26,12 @@ def test_operator_matches_golden(pkg, hiplib, op, name, monkeypatch):
     # every case whose shape allows it runs through it (others fall back to the naive kernel)
     monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0")
     c = cases.build(name, pkg)
+    fused_before = hiplib.fdtd_hip_fused_launch_count()
     rc, prof = pkg.run_operator(getattr(hiplib, op), c["m"], c["src"], c["coords"], c["u"], **c["kw"])
     assert rc == 0
+    # the 512-wide cases are there for the two-steps-per-sweep kernel: make sure it is what ran
+    took_fused = hiplib.fdtd_hip_fused_launch_count() > fused_before
+    assert took_fused == (name.startswith("fused_z512") and op == "Kernel_CUDA_Optimized")
     # up to 128 sources the scatter is ordered like the reference's serial loop, so even coincident
     # scatter targets (ricker30_n24_overlap) are bit-exact
     check_against_golden(name, c["u"], exact=True)
