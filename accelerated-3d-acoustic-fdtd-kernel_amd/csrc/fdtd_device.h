@@ -55,6 +55,7 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
                       int gx_m, int gx_M, void *stream);
 
 // fdtd_march2.hip: can the two-steps-per-sweep kernel take this problem?
+bool fdtd_march2_preferred(const struct fdtd_geom *g);
 bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float *b, const float *a_prev,
                           const float *c, const float *d, int nsrc);
 int fdtd_shells_differ(const struct fdtd_geom *g, const float *a, const float *b, int *flag, void *stream);

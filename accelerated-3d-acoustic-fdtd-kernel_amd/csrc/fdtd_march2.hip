@@ -25,8 +25,9 @@
 // counted waits).  Memory is addressed with buffer instructions: descriptor (scalar) + plane
 // offset (scalar) + one loop-invariant 32-bit lane offset per row.
 //
-// Shapes: z extent exactly 512 cells, y extent a multiple of 8, at most 8 sources; anything else
-// is run as two single sweeps by fdtd_hip_two_steps.
+// Shapes: z extent 512 cells with a y extent that is a multiple of 8, or z extent 256 with a y
+// extent that is a multiple of 16 (the workgroup then carries two 8-row tiles, one per wave
+// parity); at most 8 sources; anything else is run as two single sweeps by fdtd_hip_two_steps.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -130,7 +131,10 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
   return f32x4{olo.x, olo.y, ohi.x, ohi.y};
 }
 
-template <bool NT>
+// ZH = 2: rows of 512 cells, the two waves (q, 0) and (q, 1) hold the two z-halves of the same rows.
+// ZH = 1: rows of 256 cells; the workgroup then carries two independent 8-row tiles stacked in y,
+// h selects the tile (each computes its own redundant rows; the LDS columns 0..63 / 64..127 are theirs).
+template <bool NT, int ZH>
 __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt) {
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int h = wave & 1, q = wave >> 1;
   const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int yt = t % nyt, xc = t / nyt;
-  const int yb = a.y_m + yt * M2_ROWS;
+  const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (2 * yt + h) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
   const Coef2 k = a.k;
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const bool seg2_outside = yrow[2] < a.y_m || yrow[2] > a.y_M;
   const int yhalo = q < 2 ? yb - 4 + q : yb + 8 + q;   // B row outside the 12-row stack
   const int hslot = q < 2 ? q : 12 + q;
-  const int lz = h * 64 + lane;                         // float4 index inside the 512-cell row
+  const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
+  const int lz = ZH == 2 ? lc : lane;                   // float4 index inside the row of cells
   // Addresses: descriptor base + scalar offset (plane + row, wave-uniform) + one lane offset along z.
   // vz: the lane's 4 cells; vze: the 2 cells before them, or behind them in the last lane; vzc: the
   // same for the C array, where only the two cells before lane 0 / behind lane 63 are ever used, so
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const rsrc_t rC = make_rsrc(a.C + base, 0xffffffffu), rD = make_rsrc(a.D + base, 0xffffffffu);
   int sp = 2 * sxb;   // byte offset of plane p
 
-  // ---- source corners of the first step: lane l holds corner l (source l / 8, corner l % 8) ----
+  // ---- source corners: lane l holds corner l (source l / 8, corner l % 8) with its value for the
+  // scatter of the first step (into C) and of the second step (into D) ----
   bool cvalid = false;
   int cx = 0, cy = 0, cz = 0;
   float cval = 0.f, cval2 = 0.f;
@@ -235,9 +241,9 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, (sp + (i - 2) * sxb) + rowoff[s], vz);
-    av[s] = s == 0 ? LD4S(rA, (sp) + rowoff[s], vz) : LD4(rA, (sp) + rowoff[s], vz);
-    mv[s] = s == 0 ? LD4S(rM, (sp) + rowoff[s], vz) : LD4(rM, (sp) + rowoff[s], vz);
-    be[s] = LD2(rB, (sp) + rowoff[s], vze);
+    av[s] = s == 0 ? LD4S(rA, sp + rowoff[s], vz) : LD4(rA, sp + rowoff[s], vz);
+    mv[s] = s == 0 ? LD4S(rM, sp + rowoff[s], vz) : LD4(rM, sp + rowoff[s], vz);
+    be[s] = LD2(rB, sp + rowoff[s], vze);
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -248,12 +254,12 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   }
   bh = LD4(rB, (sp + sxb) + rowoff_h, vz);
   bh2 = LD4(rB, (sp + 2 * sxb) + rowoff_h, vz);
-  ch = seg2_outside ? LD4(rC, (sp) + rowoff[2], vz) : f32x4{0, 0, 0, 0};
+  ch = seg2_outside ? LD4(rC, sp + rowoff[2], vz) : f32x4{0, 0, 0, 0};
   {  // B(p0): own rows and the outside row
     const int buf = p0 & 1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) Bbuf[buf][cslot[s] + 2][lz] = bc[2][s];
-    Bbuf[buf][hslot][lz] = LD4(rB, (sp) + rowoff_h, vz);
+    for (int s = 0; s < 3; ++s) Bbuf[buf][cslot[s] + 2][lc] = bc[2][s];
+    Bbuf[buf][hslot][lc] = LD4(rB, sp + rowoff_h, vz);
   }
   __syncthreads();
   int ring_w = ((p0 % 3) + 3) % 3;        // ring slot written this iteration (plane p)
@@ -283,27 +289,30 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
       // ---- C(p) ----
       f32x4 cnew;
       if (plane_inside) {
-        const f32x4 ym2 = Bbuf[buf][r][lz], ym1 = Bbuf[buf][r + 1][lz];
-        const f32x4 yp1 = Bbuf[buf][r + 3][lz], yp2 = Bbuf[buf][r + 4][lz];
+        const f32x4 ym2 = Bbuf[buf][r][lc], ym1 = Bbuf[buf][r + 1][lc];
+        const f32x4 yp1 = Bbuf[buf][r + 3][lc], yp2 = Bbuf[buf][r + 4][lc];
         cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
                           mv[s]);
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
         if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
       } else {   // halo plane of the domain: the intermediate level keeps what memory holds there
-        cnew = LD4(rC, (sp) + rowoff[s], vz);
+        cnew = LD4(rC, sp + rowoff[s], vz);
       }
       if constexpr (s < 2) {
-        if (store_c) st4<NT>(rC, (sp) + rowoff[s], vz, cnew);
+        if (store_c) st4<NT>(rC, sp + rowoff[s], vz, cnew);
       }
-      Cring[ring_w][r][lz] = cnew;
+      Cring[ring_w][r][lc] = cnew;
       // ---- D(p-2) ----
       if constexpr (s < 2) {
         if (do_d) {
-          const f32x4 ym2 = Cring[ring_r][r - 2][lz], ym1 = Cring[ring_r][r - 1][lz];
-          const f32x4 yp1 = Cring[ring_r][r + 1][lz], yp2 = Cring[ring_r][r + 2][lz];
-          const f32x4 nb = Cring[ring_r][r][h ? 63 : 64];   // the other z-half of the same row
-          const f32x2 eL = h ? f32x2{nb.z, nb.w} : ce[s];
-          const f32x2 eR = h ? ce[s] : f32x2{nb.x, nb.y};
+          const f32x4 ym2 = Cring[ring_r][r - 2][lc], ym1 = Cring[ring_r][r - 1][lc];
+          const f32x4 yp1 = Cring[ring_r][r + 1][lc], yp2 = Cring[ring_r][r + 2][lc];
+          f32x2 eL = ce[s], eR = ce[s];
+          if constexpr (ZH == 2) {   // the other z-half of the same row is in LDS
+            const f32x4 nb = Cring[ring_r][r][h ? 63 : 64];
+            if (h) eL = f32x2{nb.z, nb.w};
+            else eR = f32x2{nb.x, nb.y};
+          }
           f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
                                PB(0)[s], mh[0][s]);
           if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
@@ -327,19 +336,19 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
       const int r = cslot[s];
       if constexpr (s < 2) ce[s] = LD2(rC, (sq - 2 * sxb) + rowoff[s], vzc);   // C array, plane (p+1)-2
       if (STEADY) {
-        Bbuf[buf ^ 1][r + 2][lz] = PB(3)[s];           // B(p+1), centre plane of the next iteration
+        Bbuf[buf ^ 1][r + 2][lc] = PB(3)[s];           // B(p+1), centre plane of the next iteration
         PB(0)[s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);     // B(p+3) replaces B(p-2)
       } else {
         bc[0][s] = bc[1][s];
         bc[1][s] = bc[2][s];
         bc[2][s] = bc[3][s];
         bc[3][s] = bc[4][s];
-        Bbuf[buf ^ 1][r + 2][lz] = bc[2][s];
+        Bbuf[buf ^ 1][r + 2][lc] = bc[2][s];
         bc[4][s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);
       }
-      av[s] = s == 0 ? LD4S(rA, (sq) + rowoff[s], vz) : LD4(rA, (sq) + rowoff[s], vz);
-      mv[s] = s == 0 ? LD4S(rM, (sq) + rowoff[s], vz) : LD4(rM, (sq) + rowoff[s], vz);
-      be[s] = LD2(rB, (sq) + rowoff[s], vze);
+      av[s] = s == 0 ? LD4S(rA, sq + rowoff[s], vz) : LD4(rA, sq + rowoff[s], vz);
+      mv[s] = s == 0 ? LD4S(rM, sq + rowoff[s], vz) : LD4(rM, sq + rowoff[s], vz);
+      be[s] = LD2(rB, sq + rowoff[s], vze);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -353,10 +362,10 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     reload(S2{});
     compute(S0{});
     reload(S0{});
-    Bbuf[buf ^ 1][hslot][lz] = bh;
+    Bbuf[buf ^ 1][hslot][lc] = bh;
     bh = bh2;
     bh2 = LD4(rB, (sq + 2 * sxb) + rowoff_h, vz);
-    if (seg2_outside) ch = LD4(rC, (sq) + rowoff[2], vz);
+    if (seg2_outside) ch = LD4(rC, sq + rowoff[2], vz);
     __syncthreads();
     ring_w = ring_w == 2 ? 0 : ring_w + 1;
     ring_r = ring_r == 2 ? 0 : ring_r + 1;
@@ -444,7 +453,9 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
                           const float *c, const float *d, int nsrc) {
   if (!g) return false;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
-  if (ex < 1 || ez != M2_ZCELLS || ey < M2_ROWS || ey % M2_ROWS) return false;
+  // rows of 512 cells in tiles of 8 rows, or rows of 256 cells in pairs of such tiles
+  const int tile_rows = ez == M2_ZCELLS ? M2_ROWS : 2 * M2_ROWS;
+  if (ex < 1 || (ez != M2_ZCELLS && ez != M2_ZCELLS / 2) || ey < tile_rows || ey % tile_rows) return false;
   if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
   if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
   if (((long)g->nyp * g->nzp) % 4) return false;
@@ -454,6 +465,15 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
   if (g->z_M + FDTD_HALO + 2 > g->nzp - 1) return false;
   if (nsrc > M2_MAX_SRC) return false;
   return true;
+}
+
+// Does the automatic choice take the fused kernel for an eligible problem?  Rows of 512 cells over
+// at least FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of
+// u(time+1) each chunk recomputes, and with rows of 256 cells the marching kernel was the faster one
+// where measured (256^3: 300 against 253 Gcells/s), so those are fused only on explicit request.
+bool fdtd_march2_preferred(const struct fdtd_geom *g) {
+  const int ex = g->x_M - g->x_m + 1, ez = g->z_M - g->z_m + 1;
+  return ez == M2_ZCELLS && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 
 // Two steps (time, time + 1) on four level buffers: cur = u(time), prev = u(time-1) are read,
@@ -492,7 +512,9 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // many x-chunks as fill 256 workgroups; long x ranges are cut into several launches so that
   // workgroups march at most ~128 planes side by side (they drift apart beyond that and stop
   // finding each other's rows in L2).
-  const int nyt = ey / M2_ROWS > 0 ? ey / M2_ROWS : 1;
+  const int ez = g->z_M - g->z_m + 1;
+  const int tile_rows = ez == M2_ZCELLS ? M2_ROWS : 2 * M2_ROWS;
+  const int nyt = ey / tile_rows > 0 ? ey / tile_rows : 1;
   const int nxc = nyt >= 256 ? 1 : (256 + nyt / 2) / nyt;
   int xchunk = env_int2("FDTD_FUSE2_XCHUNK", 0);
   if (xchunk <= 0) {
@@ -509,7 +531,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
                     env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok &&
                     fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
-                    (variant == FDTD_VARIANT_MARCH2 || ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32));
+                    (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g));
 
   // corners of either scatter that land in the halo layer: applied to memory by the call that owns
   // their plane (the sweeps never write there and read next1's halo like any other halo value)
@@ -600,10 +622,14 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     al.x_m = x0;
     al.x_M = x0 + nxc * xchunk - 1 < g->x_M ? x0 + nxc * xchunk - 1 : g->x_M;
     const int chunks = (al.x_M - al.x_m + xchunk) / xchunk;
-    if (nt)
-      hipLaunchKernelGGL((stencil_march2_kernel<true>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
-    else
-      hipLaunchKernelGGL((stencil_march2_kernel<false>), dim3((unsigned)(nyt * chunks)), dim3(512), 0, s, al, xchunk, nyt);
+    const dim3 grid((unsigned)(nyt * chunks)), block(512);
+    if (ez == M2_ZCELLS) {
+      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, al, xchunk, nyt);
+      else hipLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, al, xchunk, nyt);
+    } else {
+      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, al, xchunk, nyt);
+      else hipLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, al, xchunk, nyt);
+    }
     __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
   }
   const int rc = (int)hipGetLastError();

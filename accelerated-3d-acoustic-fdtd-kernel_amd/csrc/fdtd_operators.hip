@@ -212,8 +212,7 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
     const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
     float *uf = (float *)u;
     const char *e = getenv("FDTD_FUSE2");
-    const int ex = g->x_M - g->x_m + 1;
-    if ((!e || atoi(e) != 0) && (variant == FDTD_VARIANT_MARCH2 || ex >= 32) &&
+    if ((!e || atoi(e) != 0) && (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g)) &&
         fdtd_march2_eligible(g, m, uf, uf + vol, uf + 2 * vol, uf, has_src ? p_src_M - p_src_m + 1 : 0))
       return time_loop_fused(g, m, src, src_coords, uf, p_src_m, p_src_M, src_stride, coord_stride, time_m,
                              time_M, variant, s, timers, has_src);

@@ -449,7 +449,8 @@ class HipStepper:
         if os.environ.get("FDTD_SLAB_OVERLAP", "1") == "0":
             return False
         nyp, nzp = prop.levels[0].shape[1:]
-        return (nzp - 2 * HALO == 512 and (nyp - 2 * HALO) % 8 == 0 and prop.nsrc <= 8
+        nz, ny = nzp - 2 * HALO, nyp - 2 * HALO
+        return (((nz == 512 and ny % 8 == 0) or (nz == 256 and ny % 16 == 0)) and prop.nsrc <= 8
                 and os.environ.get("FDTD_FUSE2", "1") != "0" and self.variant in (-1, abi.VARIANTS["march2"]))
 
     def bind_pairs(self, prop):

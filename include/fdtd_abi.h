@@ -165,7 +165,10 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * bit for bit that of two single steps.  This is the time fusion the reference driver
  * has a knob for (t_fuse, main.cpp:261,267) and no reference kernel implements.
  * next2 must not alias prev.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
- * the fusion, any other variant selects the single-step kernel used for both sweeps. */
+ * the fusion, any other variant selects the single-step kernel used for both sweeps.
+ * FDTD_VARIANT_MARCH2 fuses regardless of the x range and also takes a z extent of 256
+ * with a y extent that is a multiple of 16 (AUTO leaves those to the single-step kernel,
+ * which is faster there). */
 int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
                        const float *src_coords, const float *cur, const float *prev,
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,

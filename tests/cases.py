@@ -56,6 +56,8 @@ CASES = {
     # the fused sweep on a box strictly inside the arrays: x 2..37, y 8..23, z 4..515 of 40 x 32 x 520
     "fused_z512_subrange": ("random", dict(n=(40, 32, 520), nt=9, nsrc=2, h=(1.0, 1.0, 1.0), seed=24,
                                            bounds=(2, 37, 8, 23, 4, 515))),
+    # rows of 256 cells: the fused sweep carries two 8-row tiles per workgroup (y extent a multiple of 16)
+    "fused_z256": ("random", dict(n=(36, 32, 256), nt=10, nsrc=3, h=(1.1, 1.0, 0.9), seed=25, edge_source=True)),
     "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
     "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
 }

@@ -25,13 +25,16 @@ def test_operator_matches_golden(pkg, hiplib, op, name, monkeypatch):
     # the fast operator picks its kernel by problem size; force the marching kernel here so that
     # every case whose shape allows it runs through it (others fall back to the naive kernel)
     monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0")
+    if name.startswith("fused_z256"):
+        # rows of 256 cells take the two-steps-per-sweep kernel only on explicit request
+        monkeypatch.setenv("FDTD_VARIANT", "march2")
     c = cases.build(name, pkg)
     fused_before = hiplib.fdtd_hip_fused_launch_count()
     rc, prof = pkg.run_operator(getattr(hiplib, op), c["m"], c["src"], c["coords"], c["u"], **c["kw"])
     assert rc == 0
-    # the 512-wide cases are there for the two-steps-per-sweep kernel: make sure it is what ran
+    # the fused_z* cases are there for the two-steps-per-sweep kernel: make sure it is what ran
     took_fused = hiplib.fdtd_hip_fused_launch_count() > fused_before
-    assert took_fused == (name.startswith("fused_z512") and op == "Kernel_CUDA_Optimized")
+    assert took_fused == (name.startswith("fused_z") and op == "Kernel_CUDA_Optimized")
     # up to 128 sources the scatter is ordered like the reference's serial loop, so even coincident
     # scatter targets (ricker30_n24_overlap) are bit-exact
     check_against_golden(name, c["u"], exact=True)
@@ -220,12 +223,13 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
 
 
 @pytest.mark.parametrize("shape,nsrc,variant", [((70, 64, 512), 3, "auto"), ((20, 16, 512), 2, "march2"),
+                                                ((48, 64, 256), 2, "march2"), ((300, 256, 256), 1, "march2"),
                                                 ((24, 8, 512), 0, "march2"), ((520, 512, 512), 1, "auto")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
-    one launch, forced fusion on a short x range, no sources, and an x range long enough to be cut
-    into two launches (520 planes at 64 y-tiles)."""
+    one launch, forced fusion on a short x range, rows of 256 cells (fused on request only), no
+    sources, and an x range long enough to be cut into two launches (520 planes at 64 y-tiles)."""
     import torch
     nx, ny, nz = shape
     gen = torch.Generator(device="cuda").manual_seed(1234)
@@ -252,7 +256,9 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
         torch.cuda.synchronize()
         return n1, n2
 
+    before = hiplib.fdtd_hip_fused_launch_count()
     f1, f2 = run(variant)
+    assert hiplib.fdtd_hip_fused_launch_count() > before
     s1, s2 = run("naive")
     assert torch.equal(f1.view(torch.int32), s1.view(torch.int32))
     assert torch.equal(f2.view(torch.int32), s2.view(torch.int32))
