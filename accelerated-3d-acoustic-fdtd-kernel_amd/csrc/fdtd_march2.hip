@@ -25,9 +25,13 @@
 // counted waits).  Memory is addressed with buffer instructions: descriptor (scalar) + plane
 // offset (scalar) + one loop-invariant 32-bit lane offset per row.
 //
-// Shapes: z extent 512 cells with a y extent that is a multiple of 8, or z extent 256 with a y
-// extent that is a multiple of 16 (the workgroup then carries two 8-row tiles, one per wave
+// Shapes: z extent a multiple of 512 cells with a y extent that is a multiple of 8, or z extent 256
+// with a y extent that is a multiple of 16 (the workgroup then carries two 8-row tiles, one per wave
 // parity); at most 8 sources; anything else is run as two single sweeps by fdtd_hip_two_steps.
+// Rows longer than 512 cells are cut into z-tiles of 512.  A tile cannot know its neighbour's C
+// beyond the cut in time, so the four D cells around every cut (two on either side) come out wrong
+// and are recomputed by seam_kernel after the sweep, from the C level in memory; the second scatter
+// then runs as a launch of its own after that.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -64,6 +68,7 @@ struct March2Args {
   const float *m_f;
   int nsrc, p_src_m, coord_stride;
   int z_M;
+  int scatter_d;      // 0: the second scatter is left to the caller (rows cut into z-tiles)
   int x_shift;        // source positions are in the coordinates of the whole domain: plane = position - x_shift
   float h_x, h_y, h_z, o_x, o_y, o_z;
 };
@@ -135,14 +140,15 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // ZH = 1: rows of 256 cells; the workgroup then carries two independent 8-row tiles stacked in y,
 // h selects the tile (each computes its own redundant rows; the LDS columns 0..63 / 64..127 are theirs).
 template <bool NT, int ZH>
-__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt) {
+__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt) {
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = wave & 1, q = wave >> 1;
   const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-  const int yt = t % nyt, xc = t / nyt;
+  const int yt = t % nyt, zt = (t / nyt) % nzt, xc = t / (nyt * nzt);
+  const int zb = a.z_m + zt * M2_ZCELLS;                // first cell of this z-tile
   const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (2 * yt + h) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
@@ -156,11 +162,12 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int hslot = q < 2 ? q : 12 + q;
   const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
   const int lz = ZH == 2 ? lc : lane;                   // float4 index inside the row of cells
+  const bool seam_lane = ZH == 2 && ((lc == 0 && zt > 0) || (lc == 127 && zt < nzt - 1));   // next to a z-cut
   // Addresses: descriptor base + scalar offset (plane + row, wave-uniform) + one lane offset along z.
   // vz: the lane's 4 cells; vze: the 2 cells before them, or behind them in the last lane; vzc: the
   // same for the C array, where only the two cells before lane 0 / behind lane 63 are ever used, so
   // the lanes in between repeat lane 0's address instead of touching the whole row.
-  const unsigned vz = (unsigned)(a.z_m + lz * 4 + FDTD_HALO) * 4u;
+  const unsigned vz = (unsigned)(zb + lz * 4 + FDTD_HALO) * 4u;
   const unsigned vze = lane == 63 ? vz + 16u : vz - 8u;
   const unsigned vzc = lane == 63 ? vz + 16u : vz - (unsigned)lane * 16u - 8u;
   int rowoff[3];   // byte offset of the segment's row inside a plane
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
       mask &= mask - 1;
       const int sy_ = __builtin_amdgcn_readlane(cy, b), sz_ = __builtin_amdgcn_readlane(cz, b);
       const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), b));
-      const int zi = sz_ - a.z_m;
+      const int zi = sz_ - zb;
       const bool hit = sy_ == yr && (zi >> 2) == lz;
       const int comp = zi & 3;
       const f32x4 added = v + f32x4{sv, sv, sv, sv};
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     const int d = p - 2;
     const bool do_d = STEADY ? true : (d >= x_begin && d <= x_end);
     const unsigned long cmask = __ballot(cvalid && cx == p);       // corners of the first scatter in plane p
-    const unsigned long dmask = __ballot(cvalid && cx == p - 2);   // corners of the second scatter in plane p-2
+    const unsigned long dmask = __ballot(cvalid && a.scatter_d && cx == p - 2);   // second scatter, plane p-2
 
     auto compute = [&](auto seg) __attribute__((always_inline)) {
       constexpr int s = decltype(seg)::value;
@@ -300,6 +307,9 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
       }
       if constexpr (s < 2) {
         if (store_c) st4<NT>(rC, sp + rowoff[s], vz, cnew);
+        // planes before and behind the chunk: their C exists only here, and seam_kernel needs it
+        // next to the z-cuts (a chunk beside this one, or the owner of the plane, stores the same bits)
+        else if (!STEADY && plane_inside && seam_lane) st4<false>(rC, sp + rowoff[s], vz, cnew);
       }
       Cring[ring_w][r][lc] = cnew;
       // ---- D(p-2) ----
@@ -392,6 +402,30 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
 #undef LD2
 }
 
+// D on the four cells around every z-cut of the sweep above (cells cut-2 .. cut+1), from the C
+// level in memory once the sweep has completed it: same expression, same operand order.  One
+// thread per pair of cells; 128 rows x 2 pairs per workgroup, grid (row groups, cuts, planes).
+struct SeamArgs {
+  const float *C, *B, *m;
+  float *D;
+  long sx;
+  int sy, x_m, y_m, y_M, z_m;
+  Coef2 k;
+};
+__global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
+  const int j = threadIdx.x & 1, y = a.y_m + (int)blockIdx.x * 128 + (int)(threadIdx.x >> 1);
+  if (y > a.y_M) return;
+  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + ((int)blockIdx.y + 1) * M2_ZCELLS - 2 + 2 * j;
+  const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
+  auto ld = [](const float *p, long at) { return *(const f32x2 *)(p + at); };
+  const f32x2 c = ld(a.C, i), zm = ld(a.C, i - 2), zp = ld(a.C, i + 2);
+  const f32x2 zs2 = zm + zp, zs1 = f32x2{zm.y + c.y, c.x + zp.x};
+  const f32x2 o = update_pair(a.k, c, ld(a.C, i - 2 * a.sx), ld(a.C, i - a.sx), ld(a.C, i + a.sx), ld(a.C, i + 2 * a.sx),
+                              ld(a.C, i - 2 * a.sy), ld(a.C, i - a.sy), ld(a.C, i + a.sy), ld(a.C, i + 2 * a.sy), zs2, zs1,
+                              ld(a.B, i), ld(a.m, i));
+  *(f32x2 *)(a.D + i) = o;
+}
+
 // The shell: the two layers of cells around the updated box, i.e. every halo cell a sweep can
 // read (openacc.cpp:161-163) or a scatter can touch (openacc.cpp:192).  One wave per (x, y) row
 // of the box grown by 2; rows outside the box in x or y are copied whole, rows inside it only
@@ -453,9 +487,9 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
                           const float *c, const float *d, int nsrc) {
   if (!g) return false;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
-  // rows of 512 cells in tiles of 8 rows, or rows of 256 cells in pairs of such tiles
-  const int tile_rows = ez == M2_ZCELLS ? M2_ROWS : 2 * M2_ROWS;
-  if (ex < 1 || (ez != M2_ZCELLS && ez != M2_ZCELLS / 2) || ey < tile_rows || ey % tile_rows) return false;
+  // rows of k * 512 cells in tiles of 8 rows, or rows of 256 cells in pairs of such tiles
+  const int tile_rows = ez == M2_ZCELLS / 2 ? 2 * M2_ROWS : M2_ROWS;
+  if (ex < 1 || (ez % M2_ZCELLS && ez != M2_ZCELLS / 2) || ez < 1 || ey < tile_rows || ey % tile_rows) return false;
   if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
   if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
   if (((long)g->nyp * g->nzp) % 4) return false;
@@ -467,13 +501,13 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
   return true;
 }
 
-// Does the automatic choice take the fused kernel for an eligible problem?  Rows of 512 cells over
+// Does the automatic choice take the fused kernel for an eligible problem?  Rows of k * 512 cells over
 // at least FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of
 // u(time+1) each chunk recomputes, and with rows of 256 cells the marching kernel was the faster one
 // where measured (256^3: 300 against 253 Gcells/s), so those are fused only on explicit request.
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
   const int ex = g->x_M - g->x_m + 1, ez = g->z_M - g->z_m + 1;
-  return ez == M2_ZCELLS && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
+  return ez % M2_ZCELLS == 0 && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 
 // Two steps (time, time + 1) on four level buffers: cur = u(time), prev = u(time-1) are read,
@@ -513,12 +547,17 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // workgroups march at most ~128 planes side by side (they drift apart beyond that and stop
   // finding each other's rows in L2).
   const int ez = g->z_M - g->z_m + 1;
-  const int tile_rows = ez == M2_ZCELLS ? M2_ROWS : 2 * M2_ROWS;
+  const int tile_rows = ez == M2_ZCELLS / 2 ? 2 * M2_ROWS : M2_ROWS;
   const int nyt = ey / tile_rows > 0 ? ey / tile_rows : 1;
-  const int nxc = nyt >= 256 ? 1 : (256 + nyt / 2) / nyt;
+  const int nzt = ez >= M2_ZCELLS ? ez / M2_ZCELLS : 1;      // z-tiles of 512 cells
+  const int ntile = nyt * nzt;
+  const int nxc = ntile >= 256 ? 1 : (256 + ntile / 2) / ntile;
+  // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
+  const long plane_bytes = (long)g->nyp * g->nzp * 4;
+  const long addressable = ((1L << 31) - 1) / plane_bytes - 9;
   int xchunk = env_int2("FDTD_FUSE2_XCHUNK", 0);
   if (xchunk <= 0) {
-    const int per_launch_cap = 128;
+    const int per_launch_cap = addressable < 128 ? (addressable > 1 ? (int)addressable : 1) : 128;
     xchunk = (ex + nxc - 1) / nxc;
     if (xchunk > per_launch_cap) {
       const int launches = (ex + nxc * per_launch_cap - 1) / (nxc * per_launch_cap);
@@ -526,8 +565,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     }
     if (xchunk < 16) xchunk = ex < 16 ? ex : 16;   // each chunk recomputes 4 planes of C
   }
-  // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
-  const bool offsets_ok = (long)(xchunk + 9) * g->nyp * g->nzp * 4 < (1L << 31);
+  const bool offsets_ok = xchunk <= addressable;
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
                     env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok &&
                     fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
@@ -603,6 +641,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.dx_m = dx_m; a.dx_M = dx_M;
   a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
+  a.scatter_d = nzt == 1;
   a.k.cm2 = -8.33333333e-2F; a.k.cm1 = 1.333333330F; a.k.c0 = -2.50F;
   a.k.dt2 = g->dt * g->dt;
   a.k.r1 = 1.0F / (g->dt * g->dt);
@@ -622,20 +661,36 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     al.x_m = x0;
     al.x_M = x0 + nxc * xchunk - 1 < g->x_M ? x0 + nxc * xchunk - 1 : g->x_M;
     const int chunks = (al.x_M - al.x_m + xchunk) / xchunk;
-    const dim3 grid((unsigned)(nyt * chunks)), block(512);
-    if (ez == M2_ZCELLS) {
-      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, al, xchunk, nyt);
-      else hipLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, al, xchunk, nyt);
+    const dim3 grid((unsigned)(ntile * chunks)), block(512);
+    if (ez >= M2_ZCELLS) {
+      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, al, xchunk, nyt, nzt);
+      else hipLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, al, xchunk, nyt, nzt);
     } else {
-      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, al, xchunk, nyt);
-      else hipLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, al, xchunk, nyt);
+      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, al, xchunk, nyt, 1);
+      else hipLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, al, xchunk, nyt, 1);
     }
     __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
   }
-  const int rc = (int)hipGetLastError();
+  if (nzt > 1) {
+    SeamArgs sa;
+    sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2;
+    sa.sx = a.sx; sa.sy = a.sy; sa.x_m = g->x_m; sa.y_m = g->y_m; sa.y_M = g->y_M; sa.z_m = g->z_m;
+    sa.k = a.k;
+    // grid.z is limited to 65535 planes
+    for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
+      sa.x_m = x0;
+      const int planes = g->x_M - x0 + 1 < 65535 ? g->x_M - x0 + 1 : 65535;
+      hipLaunchKernelGGL(seam_kernel, dim3((unsigned)((ey + 127) / 128), (unsigned)(nzt - 1), (unsigned)planes),
+                         dim3(256), 0, s, sa);
+    }
+  }
+  int rc = (int)hipGetLastError();
   if (rc) return rc;
+  if (nzt > 1 && has_src)
+    rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
+                           x_shift, g->x_m + x_shift, g->x_M + x_shift, 2, gx_m, gx_M, stream);
   if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
-  return 0;
+  return rc;
 }
 
 extern "C" int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,

@@ -58,6 +58,10 @@ CASES = {
                                            bounds=(2, 37, 8, 23, 4, 515))),
     # rows of 256 cells: the fused sweep carries two 8-row tiles per workgroup (y extent a multiple of 16)
     "fused_z256": ("random", dict(n=(36, 32, 256), nt=10, nsrc=3, h=(1.1, 1.0, 0.9), seed=25, edge_source=True)),
+    # rows of 1024 cells: two z-tiles of 512 with a cut between cells 511 and 512; sources straddle the cut
+    # (corners at 511 | 512) and sit right beside it (corners at 510, 511)
+    "fused_z1024": ("random", dict(n=(34, 16, 1024), nt=10, nsrc=3, h=(1.0, 1.1, 0.9), seed=26, edge_source=True,
+                                   seam_sources=True)),
     "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
     "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
 }
@@ -103,6 +107,9 @@ def build(name, pkg):
             # a source in the outermost cell: its scatter reaches the first halo layer
             coords[0] = np.array([(nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2]],
                                  dtype=np.float32)
+        if p.get("seam_sources"):
+            coords[1, 2] = np.float32(511.5 * h[2])
+            coords[2, 2] = np.float32(510.25 * h[2])
         kw["time_M"] = nt - 1
     else:
         kw["time_M"] = nt - 1

@@ -224,12 +224,14 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
 
 @pytest.mark.parametrize("shape,nsrc,variant", [((70, 64, 512), 3, "auto"), ((20, 16, 512), 2, "march2"),
                                                 ((48, 64, 256), 2, "march2"), ((300, 256, 256), 1, "march2"),
-                                                ((24, 8, 512), 0, "march2"), ((520, 512, 512), 1, "auto")])
+                                                ((24, 8, 512), 0, "march2"), ((520, 512, 512), 1, "auto"),
+                                                ((20, 16, 1024), 3, "march2"), ((70, 24, 1536), 2, "auto")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
     one launch, forced fusion on a short x range, rows of 256 cells (fused on request only), no
-    sources, and an x range long enough to be cut into two launches (520 planes at 64 y-tiles)."""
+    sources, an x range long enough to be cut into two launches (520 planes at 64 y-tiles), and rows
+    of 1024 and 1536 cells (two and three z-tiles, the cells around the cuts redone by the seam pass)."""
     import torch
     nx, ny, nz = shape
     gen = torch.Generator(device="cuda").manual_seed(1234)
@@ -245,6 +247,8 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
         ext = torch.tensor([(nx - 1) * h[0], (ny - 1) * h[1], (nz - 1) * h[2]], device="cuda")
         coords = (torch.rand((nsrc, 3), device="cuda", generator=gen) * 0.9 + 0.05) * ext
         coords[0] = torch.tensor([(nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2]])   # corners in the halo layer
+        if nz > 512 and nsrc > 1:
+            coords[1, 2] = 511.5 * h[2]     # corners on either side of the cut between two z-tiles
 
     def run(var):
         cur, prev, n1, n2 = (t.clone() for t in lv)
