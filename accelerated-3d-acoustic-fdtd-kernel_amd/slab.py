@@ -450,7 +450,7 @@ class HipStepper:
             return False
         nyp, nzp = prop.levels[0].shape[1:]
         nz, ny = nzp - 2 * HALO, nyp - 2 * HALO
-        return (((nz == 512 and ny % 8 == 0) or (nz == 256 and ny % 16 == 0)) and prop.nsrc <= 8
+        return (((nz % 512 == 0 and ny % 8 == 0) or (nz == 256 and ny % 16 == 0)) and prop.nsrc <= 8
                 and os.environ.get("FDTD_FUSE2", "1") != "0" and self.variant in (-1, abi.VARIANTS["march2"]))
 
     def bind_pairs(self, prop):

@@ -119,7 +119,7 @@ def main():
         slab = pkg.slab
         # two steps per exchange (fused sweep, 4-plane ghosts) where the slab's cross-section allows it
         pairs = (args.variant in ("auto", "march2") and os.environ.get("FDTD_FUSE2", "1") != "0"
-                 and n == 512 and args.storage == "f32")
+                 and n % 512 == 0 and args.storage == "f32")
         maker = slab.standard_pair_benchmark if pairs else slab.SlabPropagator.standard_benchmark
         prop = maker(n_per_rank=n, ny=n, nz=n, nt=total_steps + 1, rank=rank, world=world, device=dev,
                      variant=variant, global_x=args.global_x, self_exchange=args.self_exchange and world == 1)
@@ -256,7 +256,7 @@ def main():
     achieved = ALGO_BYTES_PER_CELL * launch_cells / (kernel_ms * 1e-3) / 1e9  # GB/s, dominant kernel
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and not slabs and n == 512 and args.storage == "f32" and args.variant == "auto":
+    if os.path.exists(tpath) and not slabs and n % 512 == 0 and args.storage == "f32" and args.variant == "auto":
         try:
             tj = json.load(open(tpath))
             want = "stencil_march2" if updates_per_launch == 2 else "stencil_march_lds"
