@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "fdtd_device.h"
@@ -288,6 +290,120 @@ struct DeviceBuffers {
   }
 };
 
+// Transfers between the caller's pageable arrays and the device.  A plain hipMemcpy of pageable
+// memory runs at 27 GB/s towards the device and 17 GB/s back on an MI355X host, and the caller's
+// arrays cannot be page-locked in place (hipHostRegister refuses them there), so large transfers
+// go through three pinned 16 MB bounce buffers: a few host threads copy one chunk while the copy
+// engine moves the previous ones (54 GB/s either way, the rate of one pinned transfer).  The
+// reference's wrappers use plain cudaMemcpy (cuda.cu:204-214,317); the result is the same bytes.
+// FDTD_STAGING=0 selects plain hipMemcpy, FDTD_STAGE_THREADS the number of host threads (4);
+// FDTD_STAGE_CHUNK_KB and FDTD_STAGE_MIN_KB change the chunk size and the smallest staged
+// transfer (tests use them to run many small chunks).
+class StagedCopier {
+ public:
+  static constexpr int NBUF = 3;
+
+  StagedCopier() {
+    const char *e = getenv("FDTD_STAGING");
+    if (e && atoi(e) == 0) return;
+    const char *t = getenv("FDTD_STAGE_THREADS");
+    threads_ = t ? atoi(t) : 4;
+    if (threads_ < 1) threads_ = 1;
+    if (threads_ > 16) threads_ = 16;
+    const char *c = getenv("FDTD_STAGE_CHUNK_KB"), *lo = getenv("FDTD_STAGE_MIN_KB");
+    if (c && atol(c) > 0) CHUNK = (size_t)atol(c) << 10;
+    if (lo && atol(lo) >= 0) MIN_BYTES = (size_t)atol(lo) << 10;
+    enabled_ = true;
+  }
+  ~StagedCopier() { release(); }
+
+  int to_device(void *dst, const void *src, size_t bytes) { return run(dst, src, bytes, true); }
+  int to_host(void *dst, const void *src, size_t bytes) { return run(dst, src, bytes, false); }
+
+ private:
+  size_t CHUNK = size_t(16) << 20;
+  size_t MIN_BYTES = size_t(32) << 20;   // below this a plain copy is as fast
+  bool enabled_ = false, ready_ = false;
+  int threads_ = 4;
+  char *buf_[NBUF] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_[NBUF] = {nullptr, nullptr, nullptr};
+  hipStream_t stream_ = nullptr;
+
+  void release() {
+    for (int i = 0; i < NBUF; ++i) {
+      if (buf_[i]) (void)hipHostFree(buf_[i]);
+      if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+      buf_[i] = nullptr;
+      ev_[i] = nullptr;
+    }
+    if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
+    ready_ = false;
+  }
+  bool prepare() {
+    if (ready_) return true;
+    bool ok = hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < NBUF; ++i)
+      ok = hipHostMalloc((void **)&buf_[i], CHUNK, hipHostMallocDefault) == hipSuccess &&
+           hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      release();
+      enabled_ = false;   // no pinned memory to be had: plain copies from here on
+    }
+    ready_ = ok;
+    return ok;
+  }
+  void host_copy(char *dst, const char *src, size_t len) const {
+    if (threads_ == 1 || len < (size_t(1) << 20)) {
+      memcpy(dst, src, len);
+      return;
+    }
+    const size_t per = ((len + threads_ - 1) / threads_ + 4095) & ~size_t(4095);
+    std::vector<std::thread> pool;
+    for (size_t lo = per; lo < len; lo += per)
+      pool.emplace_back([=] { memcpy(dst + lo, src + lo, len - lo < per ? len - lo : per); });
+    memcpy(dst, src, per < len ? per : len);
+    for (std::thread &t : pool) t.join();
+  }
+  int run(void *dst, const void *src, size_t bytes, bool h2d) {
+    if (!enabled_ || bytes < MIN_BYTES || !prepare()) {
+      FDTD_HIP_CHECK(hipMemcpy(dst, src, bytes, h2d ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+      return 0;
+    }
+    FDTD_HIP_CHECK(hipDeviceSynchronize());   // whatever produced the source has finished
+    const size_t nch = (bytes + CHUNK - 1) / CHUNK;
+    auto len_of = [&](size_t c) { return bytes - c * CHUNK < CHUNK ? bytes - c * CHUNK : CHUNK; };
+    if (h2d) {
+      for (size_t c = 0; c < nch; ++c) {
+        const int b = (int)(c % NBUF);
+        if (c >= (size_t)NBUF) FDTD_HIP_CHECK(hipEventSynchronize(ev_[b]));   // the buffer's last transfer
+        host_copy(buf_[b], (const char *)src + c * CHUNK, len_of(c));
+        FDTD_HIP_CHECK(hipMemcpyAsync((char *)dst + c * CHUNK, buf_[b], len_of(c), hipMemcpyHostToDevice, stream_));
+        FDTD_HIP_CHECK(hipEventRecord(ev_[b], stream_));
+      }
+    } else {
+      // chunk c is on its way into a buffer while chunk c - (NBUF - 1) is copied out of another
+      for (size_t c = 0; c < nch + NBUF - 1; ++c) {
+        if (c < nch) {
+          const int b = (int)(c % NBUF);
+          FDTD_HIP_CHECK(hipMemcpyAsync(buf_[b], (const char *)src + c * CHUNK, len_of(c), hipMemcpyDeviceToHost,
+                                        stream_));
+          FDTD_HIP_CHECK(hipEventRecord(ev_[b], stream_));
+        }
+        if (c >= (size_t)(NBUF - 1)) {
+          const size_t cc = c - (NBUF - 1);
+          const int b = (int)(cc % NBUF);
+          FDTD_HIP_CHECK(hipEventSynchronize(ev_[b]));
+          host_copy((char *)dst + cc * CHUNK, buf_[b], len_of(cc));
+        }
+      }
+    }
+    FDTD_HIP_CHECK(hipStreamSynchronize(stream_));
+    return 0;
+  }
+};
+
 // Shape checks shared by the operators.  The reference trusts its caller; a wrong shape
 // there is an out-of-bounds access, here it is hipErrorInvalidValue
 // (cuda_optimized.cu:346-347 does the same for non-positive extents).
@@ -331,11 +447,20 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
   const size_t n_src = src_nonempty ? (size_t)src_vec->size[0] * src_vec->size[1] : 0;
   const size_t n_coords = src_nonempty ? (size_t)coords_vec->size[0] * coords_vec->size[1] : 0;
 
+  // FDTD_OPERATOR_TRACE=1: host-side phase times of this call on stderr
+  const bool trace = getenv("FDTD_OPERATOR_TRACE") && atoi(getenv("FDTD_OPERATOR_TRACE")) != 0;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  double t_alloc = 0, t_h2d = 0, t_loop = 0, t_d2h = 0;
   DeviceBuffers d;
+  StagedCopier copier;
   FDTD_HIP_CHECK(hipMalloc((void **)&d.u, 3 * vol * sizeof(float)));
   FDTD_HIP_CHECK(hipMalloc((void **)&d.m, vol * sizeof(float)));
-  FDTD_HIP_CHECK(hipMemcpy(d.u, u_vec->data, 3 * vol * sizeof(float), hipMemcpyHostToDevice));
-  FDTD_HIP_CHECK(hipMemcpy(d.m, m_vec->data, vol * sizeof(float), hipMemcpyHostToDevice));
+  t_alloc = now();
+  rc = copier.to_device(d.u, u_vec->data, 3 * vol * sizeof(float));
+  if (rc) return rc;
+  rc = copier.to_device(d.m, m_vec->data, vol * sizeof(float));
+  if (rc) return rc;
   if (src_nonempty) {
     FDTD_HIP_CHECK(hipMalloc((void **)&d.src, n_src * sizeof(float)));
     FDTD_HIP_CHECK(hipMalloc((void **)&d.coords, n_coords * sizeof(float)));
@@ -343,6 +468,7 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
     FDTD_HIP_CHECK(hipMemcpy(d.coords, coords_vec->data, n_coords * sizeof(float), hipMemcpyHostToDevice));
   }
 
+  t_h2d = now();
   const bool h16 = (variant == STORAGE_H16);
   if (h16) {
     FDTD_HIP_CHECK(hipMalloc(&d.u16, 3 * vol * sizeof(unsigned short)));
@@ -358,8 +484,13 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
     rc = fdtd_hip_convert_h16_to_f32(d.u16, d.u, 3 * vol, nullptr);
     if (rc) return rc;
   }
-  FDTD_HIP_CHECK(hipMemcpy(u_vec->data, d.u, 3 * vol * sizeof(float), hipMemcpyDeviceToHost));
-  return 0;
+  t_loop = now();
+  rc = copier.to_host(u_vec->data, d.u, 3 * vol * sizeof(float));
+  t_d2h = now();
+  if (trace)
+    fprintf(stderr, "[fdtd-hip] %dx%dx%d: alloc %.2f ms, to device %.2f ms, time loop %.2f ms, to host %.2f ms\n",
+            g.nxp, g.nyp, g.nzp, t_alloc - t_begin, t_h2d - t_alloc, t_loop - t_h2d, t_d2h - t_loop);
+  return rc;
 }
 
 }  // namespace

@@ -269,6 +269,21 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
     assert not torch.equal(f2, lv[3])
 
 
+@pytest.mark.parametrize("chunk_kb,threads", [("64", "1"), ("100", "3"), ("4096", "4")])
+def test_operator_staged_transfers(pkg, hiplib, chunk_kb, threads, monkeypatch):
+    """The operators move the caller's arrays through pinned bounce buffers when they are large;
+    here every transfer is staged, in chunks that do not divide the arrays (64 KB and 100 KB chunks
+    of a 2.8 MB field, the last one partial) and in a single chunk, with 1, 3 and 4 host threads."""
+    monkeypatch.setenv("FDTD_STAGE_MIN_KB", "0")
+    monkeypatch.setenv("FDTD_STAGE_CHUNK_KB", chunk_kb)
+    monkeypatch.setenv("FDTD_STAGE_THREADS", threads)
+    for name in ("noncubic_aniso", "ricker_n64"):
+        c = cases.build(name, pkg)
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
+        assert rc == 0
+        check_against_golden(name, c["u"], exact=True)
+
+
 def test_fused_time_loop_switch(pkg, hiplib, monkeypatch):
     """The time loop with and without the two-step sweep gives the same bytes as the oracle: Ricker run
     at 64 x 64 x 512, 50 steps (5 untimed single steps, 22 pairs, 1 single step), timers filled."""
