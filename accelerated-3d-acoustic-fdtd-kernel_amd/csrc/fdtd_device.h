@@ -54,6 +54,19 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
                       int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
                       int gx_m, int gx_M, void *stream);
 
+// Sweep and scatter in one launch for small grids (fdtd_kernels.hip).
+struct FdtdSmallSource {
+  int x, y, z;          // cell of the source position (openacc.cpp:185-187)
+  float px, py, pz;     // fractional parts
+  float mc;             // m at that cell
+};
+constexpr int FDTD_SMALL_MAX_SOURCES = 16;
+int fdtd_small_prepare(const struct fdtd_geom *g, const float *m, const float *src_coords, int p_src_m, int p_src_M,
+                       int coord_stride, FdtdSmallSource *table, void *stream);
+int fdtd_small_step(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1, float *u2,
+                    const FdtdSmallSource *table, const float *src_row, int nsrc, void *stream);
+bool fdtd_auto_is_naive(const struct fdtd_geom *g, const float *m, const float *u);
+
 // fdtd_march2.hip: can the two-steps-per-sweep kernel take this problem?
 bool fdtd_march2_preferred(const struct fdtd_geom *g);
 bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float *b, const float *a_prev,

@@ -830,6 +830,93 @@ static int launch_march_any(const StencilArgs &a, const void *u0, const void *u1
   return (int)hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------
+// Small grids: sweep and scatter in one launch.  Below a few million cells a step is two
+// launches of a few microseconds each and the launches are what takes the time, so the naive
+// sweep adds the source corners itself: the thread that owns a cell adds, after the update, the
+// corner of every source whose 2 x 2 x 2 corner block contains the cell, in source order
+// (openacc.cpp:176-196 visits sources in that order; one source has at most one corner per cell).
+// Only for sources whose corners all lie inside the updated box (the caller checks): corners in
+// the halo layer are not cells of any thread.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void small_prepare_kernel(InjectArgs a, FdtdSmallSource *tab) {
+  const int i = threadIdx.x;
+  if (i > a.p_src_M - a.p_src_m) return;
+  const int p = a.p_src_m + i;
+  const float gx = (-a.o_x + a.coords[(long)p * a.coord_stride + 0]) / a.h_x;
+  const float gy = (-a.o_y + a.coords[(long)p * a.coord_stride + 1]) / a.h_y;
+  const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
+  FdtdSmallSource t;
+  t.x = (int)floorf(gx); t.y = (int)floorf(gy); t.z = (int)floorf(gz);
+  t.px = -floorf(gx) + gx; t.py = -floorf(gy) + gy; t.pz = -floorf(gz) + gz;
+  t.mc = a.m[(long)(t.x + FDTD_HALO) * a.sx + (long)(t.y + FDTD_HALO) * a.sy + (t.z + FDTD_HALO)];
+  tab[i] = t;
+}
+
+__global__ __launch_bounds__(256) void stencil_small_kernel(StencilArgs a, const FdtdSmallSource *__restrict__ tab,
+                                                            const float *__restrict__ src_row, int nsrc) {
+  const int z = a.z_m + blockIdx.x * 64 + threadIdx.x;
+  const int y = a.y_m + blockIdx.y * 4 + threadIdx.y;
+  const int x = a.x_m + blockIdx.z;
+  if (z > a.z_M || y > a.y_M) return;
+  const Coef k = load_coef(a);
+  const long c = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
+  float v = update_from_global(k, a, c);
+  for (int i = 0; i < nsrc; ++i) {   // wave-uniform table reads
+    const FdtdSmallSource t = tab[i];
+    const unsigned rx = (unsigned)(x - t.x), ry = (unsigned)(y - t.y), rz = (unsigned)(z - t.z);
+    if (rx < 2u && ry < 2u && rz < 2u) {
+      // openacc.cpp:194, evaluated left to right
+      const float r0 = 1.0e-2F * ((int)rx * t.px + (1 - (int)rx) * (1 - t.px)) *
+                       ((int)ry * t.py + (1 - (int)ry) * (1 - t.py)) * ((int)rz * t.pz + (1 - (int)rz) * (1 - t.pz)) *
+                       src_row[i] / t.mc;
+      v += r0;
+    }
+  }
+  a.u2[c] = v;
+}
+
+static long g_small_steps = 0;
+
+// Fills the table of the sources p_src_m .. p_src_M (positions, weights, m at the position).
+int fdtd_small_prepare(const struct fdtd_geom *g, const float *m, const float *src_coords, int p_src_m, int p_src_M,
+                       int coord_stride, FdtdSmallSource *table, void *stream) {
+  if (!geom_valid(g) || !m || !src_coords || !table || p_src_M - p_src_m + 1 > FDTD_SMALL_MAX_SOURCES)
+    return (int)hipErrorInvalidValue;
+  InjectArgs a = {};
+  a.m = m; a.coords = src_coords;
+  a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
+  a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
+  a.p_src_m = p_src_m; a.p_src_M = p_src_M; a.coord_stride = coord_stride;
+  hipLaunchKernelGGL(small_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, table);
+  return (int)hipGetLastError();
+}
+
+// One step: u2 = update(u0, u1, m) with the corners of the table's sources added, amplitudes src_row[0 .. nsrc).
+int fdtd_small_step(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1, float *u2,
+                    const FdtdSmallSource *table, const float *src_row, int nsrc, void *stream) {
+  if (!geom_valid(g) || !m || !u0 || !u1 || !u2 || (nsrc > 0 && (!table || !src_row))) return (int)hipErrorInvalidValue;
+  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
+  if (ex <= 0 || ey <= 0 || ez <= 0) return 0;
+  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
+  const StencilArgs a = make_args(g, m, u0, u1, u2);
+  hipLaunchKernelGGL(stencil_small_kernel, dim3((ez + 63) / 64, (ey + 3) / 4, ex), dim3(64, 4, 1), 0,
+                     (hipStream_t)stream, a, table, src_row, nsrc);
+  __atomic_add_fetch(&g_small_steps, 1, __ATOMIC_RELAXED);
+  return (int)hipGetLastError();
+}
+
+// Statistics: sweep-and-scatter launches issued by this process so far.
+extern "C" long fdtd_hip_small_step_count(void) { return __atomic_load_n(&g_small_steps, __ATOMIC_RELAXED); }
+
+// Would the automatic choice run this box with the one-cell-per-thread kernel?
+bool fdtd_auto_is_naive(const struct fdtd_geom *g, const float *m, const float *u) {
+  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
+  const long cells = (long)ex * ey * ez;
+  return !(march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000) &&
+           ex >= env_int("FDTD_MARCH_MIN_PLANES", 8));
+}
+
 // One sweep on explicit level pointers (the levels need not be the three slots of one array).
 int fdtd_stencil_levels(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
                         float *u2, int variant, void *stream) {

@@ -198,6 +198,67 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
   return 0;
 }
 
+// The time loop for small grids: one launch per step (sweep and scatter in one kernel) and two
+// events around the timed window instead of three per step — at 32^3 a step is 3 us this way and
+// 13 us as two launches with their events.  section0 receives the whole window; section1 stays
+// as it is (the scatter has no time of its own).  Returns -1 when the case is not one for this loop.
+static int time_loop_small(const struct fdtd_geom *g, const float *m, const float *src, const float *src_coords,
+                           float *u, int p_src_m, int p_src_M, int src_stride, int coord_stride, int time_m,
+                           int time_M, hipStream_t s, struct profiler *timers, bool has_src) {
+  const int nsrc = has_src ? p_src_M - p_src_m + 1 : 0;
+  if (nsrc > FDTD_SMALL_MAX_SOURCES) return -1;
+  if (has_src) {   // every corner must be a cell of the updated box
+    std::vector<float> hc((size_t)nsrc * coord_stride);
+    FDTD_HIP_CHECK(hipMemcpyAsync(hc.data(), src_coords + (size_t)p_src_m * coord_stride, hc.size() * sizeof(float),
+                                  hipMemcpyDeviceToHost, s));
+    FDTD_HIP_CHECK(hipStreamSynchronize(s));
+    for (int p = 0; p < nsrc; ++p) {
+      const int posx = (int)floorf((-g->o_x + hc[(size_t)p * coord_stride + 0]) / g->h_x);
+      const int posy = (int)floorf((-g->o_y + hc[(size_t)p * coord_stride + 1]) / g->h_y);
+      const int posz = (int)floorf((-g->o_z + hc[(size_t)p * coord_stride + 2]) / g->h_z);
+      if (posx < g->x_m || posx + 1 > g->x_M || posy < g->y_m || posy + 1 > g->y_M || posz < g->z_m ||
+          posz + 1 > g->z_M)
+        return -1;
+    }
+  }
+  struct Owned {
+    FdtdSmallSource *table = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~Owned() {
+      if (table) (void)hipFree(table);
+      for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    }
+  } own;
+  if (has_src) {
+    FDTD_HIP_CHECK(hipMalloc((void **)&own.table, nsrc * sizeof(FdtdSmallSource)));
+    const int rc = fdtd_small_prepare(g, m, src_coords, p_src_m, p_src_M, coord_stride, own.table, s);
+    if (rc) return rc;
+  }
+  const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
+  const int first_timed = time_m + FDTD_WARMUP_STEPS;
+  const bool timed = timers && time_M >= first_timed;
+  if (timed) {
+    FDTD_HIP_CHECK(hipEventCreate(&own.ev[0]));
+    FDTD_HIP_CHECK(hipEventCreate(&own.ev[1]));
+  }
+  for (int time = time_m; time <= time_M; ++time) {
+    const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3, t2 = (((time + 1) % 3) + 3) % 3;
+    if (timed && time == first_timed) FDTD_HIP_CHECK(hipEventRecord(own.ev[0], s));
+    const int rc = fdtd_small_step(g, m, u + t0 * vol, u + t1 * vol, u + t2 * vol, own.table,
+                                   has_src ? src + (size_t)time * src_stride + p_src_m : nullptr, nsrc, s);
+    if (rc) return rc;
+  }
+  if (timed) FDTD_HIP_CHECK(hipEventRecord(own.ev[1], s));
+  FDTD_HIP_CHECK(hipStreamSynchronize(s));
+  if (timed) {
+    float ms = 0.f;
+    FDTD_HIP_CHECK(hipEventElapsedTime(&ms, own.ev[0], own.ev[1]));
+    timers->section0 += ms * 1e-3;
+  }
+  return 0;
+}
+
 // `h16` selects the binary16-storage kernels; u then points at __half data.
 static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, const float *src,
                           const float *src_coords, void *u, int p_src_m, int p_src_M,
@@ -220,6 +281,17 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
                              time_M, variant, s, timers, has_src);
   }
   if (variant == FDTD_VARIANT_MARCH2) variant = FDTD_VARIANT_AUTO;
+
+  // small grids: one launch per step
+  if (!h16 && variant == FDTD_VARIANT_AUTO && time_M >= time_m && g->x_M >= g->x_m && g->y_M >= g->y_m &&
+      g->z_M >= g->z_m && fdtd_auto_is_naive(g, m, (const float *)u)) {
+    const char *e = getenv("FDTD_SMALL_FUSED");
+    if (!e || atoi(e) != 0) {
+      const int rc = time_loop_small(g, m, src, src_coords, (float *)u, p_src_m, p_src_M, src_stride, coord_stride,
+                                     time_m, time_M, s, timers, has_src);
+      if (rc >= 0) return rc;
+    }
+  }
 
   // Three events per timed step: before the stencil, between the sections, after the
   // scatter.  They are recorded on the stream without any host synchronisation; the
@@ -522,9 +594,14 @@ static int optimized_variant() {
   return FDTD_VARIANT_AUTO;
 }
 
+// The driver's t_fuse knob ("temporal fusion steps per load", main.cpp:261,267-272; 1 unless
+// FDTD_TFUSE is set): 2 or more asks for the two-steps-per-sweep kernel whatever the x extent; at
+// 1 the choice stays automatic (the results are the same bits either way, FDTD_FUSE2=0 forbids it).
 extern "C" int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS) {
   (void)devicerm;
-  return FDTD_FORWARD(optimized_variant());
+  int variant = optimized_variant();
+  if (variant == FDTD_VARIANT_AUTO && g_cfg_t_fuse >= 2) variant = FDTD_VARIANT_MARCH2;
+  return FDTD_FORWARD(variant);
 }
 
 extern "C" int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS) {

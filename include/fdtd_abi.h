@@ -96,9 +96,11 @@ int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS);
 int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS);
 
 /* Optional hook the reference driver looks up as a weak symbol and calls once per
- * benchmark sweep (main.cpp:84,266-276).  t_fuse/nfields/use_tc select nothing in
- * this engine (no tensor-core path exists for a 13-point star); the call records the
- * values and returns. */
+ * benchmark sweep (main.cpp:84,266-276).  The call records the values and returns.
+ * t_fuse >= 2 makes Kernel_CUDA_Optimized take the two-steps-per-sweep kernel whatever
+ * the x extent (at 1, the driver's default, the choice is automatic; the results are
+ * the same bits).  use_tc and nfields select nothing: no tensor-core path exists for a
+ * 13-point star, and the operators take one field. */
 void FDTD_SetRuntimeConfig(int use_tc, int t_fuse, int nfields);
 
 /* ---------------------------------------------------------------------------
@@ -177,6 +179,10 @@ int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *s
 /* Statistics: how many two-step sweep kernels this process has launched so far (tells a
  * caller whether its calls were fused or ran as two sweeps). */
 long fdtd_hip_fused_launch_count(void);
+
+/* Statistics: how many sweep-and-scatter launches (the one-launch-per-step time loop the
+ * operators and fdtd_hip_time_loop use on small grids) this process has issued so far. */
+long fdtd_hip_small_step_count(void);
 
 /* The same with two extras for callers that measure or know more: ev_begin / ev_end
  * (hipEvent_t, may be NULL) are recorded right before the first and right after the last

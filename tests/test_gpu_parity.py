@@ -284,19 +284,70 @@ def test_operator_staged_transfers(pkg, hiplib, chunk_kb, threads, monkeypatch):
         check_against_golden(name, c["u"], exact=True)
 
 
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_small_grid_time_loop(pkg, hiplib, name):
+    """Default settings: grids below the marching kernel's threshold go through the one-launch-per-step
+    loop (sweep and scatter in one kernel) unless a source corner lands in the halo layer or the fused
+    two-step sweep takes the case; the bytes are the fixture's either way, timers cover the timed window."""
+    c = cases.build(name, pkg)
+    before = hiplib.fdtd_hip_small_step_count()
+    rc, prof = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
+    assert rc == 0
+    check_against_golden(name, c["u"], exact=True)
+    kind, p = cases.CASES[name]
+    time_M = c["kw"].get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
+    n_steps = time_M - c["kw"].get("time_m", 0) + 1
+    bounds = c["kw"].get("bounds")
+    empty = n_steps <= 0 or (bounds is not None and bounds[1] < bounds[0])
+    inside = True   # every source corner is a cell of the updated box
+    if c["src"] is not None:
+        n = c["u"].shape[1:]
+        b = bounds if bounds is not None else (0, n[0] - 9, 0, n[1] - 9, 0, n[2] - 9)
+        h = np.asarray(c["kw"].get("h", (0.1, 0.1, 0.1)), dtype=np.float32)
+        lo, hi = c["kw"].get("p_src", (0, c["coords"].shape[0] - 1))
+        pos = np.floor(c["coords"][lo:hi + 1].astype(np.float32) / h).astype(int)
+        for d in range(3):
+            inside &= bool(np.all(pos[:, d] >= b[2 * d]) and np.all(pos[:, d] + 1 <= b[2 * d + 1]))
+    fused = name.startswith("fused_z512") or name.startswith("fused_z1024")
+    expected = inside and not (fused or empty or p.get("nsrc", 0) > 16)
+    assert hiplib.fdtd_hip_small_step_count() - before == (n_steps if expected else 0), name
+    assert (prof.section0 > 0) == (n_steps > pkg.WARMUP_STEPS)
+
+
+def test_t_fuse_knob_requests_fused_sweep(pkg, hiplib):
+    """FDTD_SetRuntimeConfig(use_tc, t_fuse, nfields), the driver's hook (main.cpp:84,272): with
+    t_fuse = 2 the optimized operator fuses even an x range of 20 planes, with 1 it does not; both
+    give the oracle's bits."""
+    n = (20, 16, 512)
+    u_ref, m, src, coords = pkg.standard_inputs(*n, 12, 1)
+    ob.run_oracle(m, src, coords, u_ref)
+    try:
+        for t_fuse, expect in ((2, True), (1, False)):
+            hiplib.FDTD_SetRuntimeConfig(0, t_fuse, 1)
+            before = hiplib.fdtd_hip_fused_launch_count()
+            u = np.zeros_like(u_ref)
+            rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u)
+            assert rc == 0
+            assert (hiplib.fdtd_hip_fused_launch_count() > before) == expect
+            assert ob.bits_equal(u, u_ref)
+    finally:
+        hiplib.FDTD_SetRuntimeConfig(0, 1, 1)
+
+
 def test_fused_time_loop_switch(pkg, hiplib, monkeypatch):
-    """The time loop with and without the two-step sweep gives the same bytes as the oracle: Ricker run
+    """The time loop with the two-step sweep, with the small-grid loop and with neither gives the same bytes as the oracle: Ricker run
     at 64 x 64 x 512, 50 steps (5 untimed single steps, 22 pairs, 1 single step), timers filled."""
     n = (64, 64, 512)
     u_ref, m, src, coords = pkg.standard_inputs(*n, 50, 1)
     ob.run_oracle(m, src, coords, u_ref)
-    for fuse in ("1", "0"):
+    for fuse, small in (("1", "1"), ("0", "1"), ("0", "0")):
         monkeypatch.setenv("FDTD_FUSE2", fuse)
+        monkeypatch.setenv("FDTD_SMALL_FUSED", small)   # 2 M cells: without the fused sweep, the small-grid loop
         u = np.zeros_like(u_ref)
         rc, prof = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u)
         assert rc == 0
-        assert ob.bits_equal(u, u_ref), f"FDTD_FUSE2={fuse}"
-        assert prof.section0 > 0 and prof.section1 > 0
+        assert ob.bits_equal(u, u_ref), f"FDTD_FUSE2={fuse} FDTD_SMALL_FUSED={small}"
+        assert prof.section0 > 0 and (prof.section1 > 0 or (fuse, small) == ("0", "1"))
 
 
 def test_run_wrappers(pkg, hiplib):
