@@ -46,6 +46,54 @@ struct EventPool {
   }
 };
 
+// section0 / section1 of a timed window of `units` units (steps, or pairs of steps).  The window
+// as a whole is timed by two events; the split between the sections comes from event triples
+// (before the sweep, between the sections, after the scatter) recorded around every stride-th
+// unit, because three events per unit cost about 11 us per unit on the stream — a tenth of a
+// step at 256^3.  stride 1 (windows of up to 8 units, or FDTD_TIMER_STRIDE=1) records every
+// unit and sums the intervals themselves, which is what the reference's wrappers do
+// (cuda.cu:237-262 brackets each kernel); default stride 4.
+struct SectionTimer {
+  EventPool pool;
+  int stride = 1, units = 0;
+  int init(int n_units) {
+    units = n_units;
+    if (units <= 0) return 0;
+    const char *e = getenv("FDTD_TIMER_STRIDE");
+    stride = e ? atoi(e) : (units <= 8 ? 1 : 4);
+    if (stride < 1) stride = 1;
+    return pool.make((size_t)((units + stride - 1) / stride) * 3 + 1);
+  }
+  // event to record at point `which` (0 before the sweep, 1 between the sections, 2 after the
+  // scatter) of unit k, or null
+  hipEvent_t at(int k, int which) const {
+    if (k < 0 || k >= units || k % stride) return nullptr;
+    return pool.ev[(size_t)(k / stride) * 3 + which];
+  }
+  hipEvent_t window_end() const { return units > 0 ? pool.ev.back() : nullptr; }
+  int finish(struct profiler *timers) const {   // after the stream has been synchronised
+    if (units <= 0) return 0;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < units; k += stride) {
+      float ms0 = 0.f, ms1 = 0.f;
+      FDTD_HIP_CHECK(hipEventElapsedTime(&ms0, at(k, 0), at(k, 1)));
+      FDTD_HIP_CHECK(hipEventElapsedTime(&ms1, at(k, 1), at(k, 2)));
+      s0 += ms0;
+      s1 += ms1;
+    }
+    if (stride > 1) {
+      float win = 0.f;
+      FDTD_HIP_CHECK(hipEventElapsedTime(&win, at(0, 0), window_end()));
+      const double f1 = (s0 + s1) > 0.0 ? s1 / (s0 + s1) : 0.0;
+      s1 = win * f1;
+      s0 = win - s1;
+    }
+    timers->section0 += s0 * 1e-3;
+    timers->section1 += s1 * 1e-3;
+    return 0;
+  }
+};
+
 }  // namespace
 
 // The time loop with two steps per sweep (fp32 storage).  Four level buffers rotate: the three
@@ -116,19 +164,21 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
 
   const int first_timed = time_m + FDTD_WARMUP_STEPS;
   const int n_timed = (timers && time_M >= first_timed) ? (time_M - first_timed + 1) : 0;
-  EventPool pool;
-  if (n_timed > 0) {
-    int rc = pool.make((size_t)n_timed * 3);
+  // timed units: pairs, and a single step at the end of an odd window
+  SectionTimer st;
+  {
+    const int rc = st.init((n_timed + 1) / 2);
     if (rc) return rc;
   }
-  int nev = 0;   // events are recorded in triples: start, end of section0, end of section1
+  int unit = 0;
   const int single = variant == FDTD_VARIANT_MARCH2 ? FDTD_VARIANT_AUTO : variant;
   int time = time_m;
   while (time <= time_M) {
     const bool timed = n_timed > 0 && time >= first_timed;
     // a pair must not straddle the start of the timed window
     const bool pair = time + 1 <= time_M && !(n_timed > 0 && time < first_timed && time + 1 >= first_timed);
-    if (timed) FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev], s));
+    const int k = timed ? unit : -1;
+    if (st.at(k, 0)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 0), s));
     if (pair) {
       if (follow) {
         const int rc = fdtd_hip_copy_shell(g, P[spare], P[prev], 0, s);
@@ -137,8 +187,7 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
       const int rc = fdtd_two_steps_impl(g, m, has_src ? src : nullptr, has_src ? src_coords : nullptr, P[cur],
                                          P[prev], P[third], P[spare], time, has_src ? p_src_m : 0,
                                          has_src ? p_src_M : -1, src_stride, coord_stride, variant,
-                                         sources_inside ? 1 : 0, 0, 0, s, nullptr, timed ? pool.ev[nev + 1] : nullptr,
-                                         nullptr, 0);
+                                         sources_inside ? 1 : 0, 0, 0, s, nullptr, st.at(k, 1), nullptr, 0);
       if (rc) return rc;
       const int ncur = spare, nprev = third, nthird = cur, nspare = prev;
       cur = ncur; prev = nprev; third = nthird; spare = nspare;
@@ -146,7 +195,7 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
     } else {
       int rc = fdtd_stencil_levels(g, m, P[cur], P[prev], P[third], single, s);
       if (rc) return rc;
-      if (timed) FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev + 1], s));
+      if (st.at(k, 1)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 1), s));
       if (has_src) {
         rc = fdtd_inject_level(g, m, src, src_coords, P[third], time, p_src_m, p_src_M, src_stride, coord_stride, 0,
                                g->x_m - 1, g->x_M + 1, 0, 0, 0, s);
@@ -156,11 +205,10 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
       cur = ncur; prev = nprev; third = nthird;
       time += 1;
     }
-    if (timed) {
-      FDTD_HIP_CHECK(hipEventRecord(pool.ev[nev + 2], s));
-      nev += 3;
-    }
+    if (st.at(k, 2)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 2), s));
+    if (timed) ++unit;
   }
+  if (st.window_end()) FDTD_HIP_CHECK(hipEventRecord(st.window_end(), s));
   // u(T+1), u(T), u(T-1) (T = time_M) go where the reference's ring leaves them; the free buffer
   // is the scratch cell of the permutation
   {
@@ -184,16 +232,8 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
   }
   FDTD_HIP_CHECK(hipStreamSynchronize(s));
   if (n_timed > 0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nev; k += 3) {
-      float ms0 = 0.f, ms1 = 0.f;
-      FDTD_HIP_CHECK(hipEventElapsedTime(&ms0, pool.ev[k], pool.ev[k + 1]));
-      FDTD_HIP_CHECK(hipEventElapsedTime(&ms1, pool.ev[k + 1], pool.ev[k + 2]));
-      s0 += ms0;
-      s1 += ms1;
-    }
-    timers->section0 += s0 * 1e-3;
-    timers->section1 += s1 * 1e-3;
+    const int rc = st.finish(timers);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -293,14 +333,13 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
     }
   }
 
-  // Three events per timed step: before the stencil, between the sections, after the
-  // scatter.  They are recorded on the stream without any host synchronisation; the
-  // elapsed times are read once after the final synchronise.
+  // Timer events (see SectionTimer) are recorded on the stream without any host
+  // synchronisation; the elapsed times are read once after the final synchronise.
   const int first_timed = time_m + FDTD_WARMUP_STEPS;
   const int n_timed = (timers && time_M >= first_timed) ? (time_M - first_timed + 1) : 0;
-  EventPool pool;
-  if (n_timed > 0) {
-    int rc = pool.make((size_t)n_timed * 3);
+  SectionTimer st;
+  {
+    const int rc = st.init(n_timed);
     if (rc) return rc;
   }
 
@@ -309,11 +348,11 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
     const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3,
               t2 = (((time + 1) % 3) + 3) % 3;
     const int k = (n_timed > 0 && time >= first_timed) ? (time - first_timed) : -1;
-    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(pool.ev[3 * k + 0], s));
+    if (st.at(k, 0)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 0), s));
     int rc = h16 ? fdtd_hip_stencil_step_h16(g, m, u, t0, t1, t2, s)
                  : fdtd_hip_stencil_step(g, m, (float *)u, t0, t1, t2, variant, s);
     if (rc) return rc;
-    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(pool.ev[3 * k + 1], s));
+    if (st.at(k, 1)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 1), s));
     if (has_src) {
       rc = h16 ? fdtd_hip_source_inject_h16(g, m, src, src_coords, u, t2, time, p_src_m, p_src_M,
                                             src_stride, coord_stride, s)
@@ -321,22 +360,11 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
                                         p_src_M, src_stride, coord_stride, s);
       if (rc) return rc;
     }
-    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(pool.ev[3 * k + 2], s));
+    if (st.at(k, 2)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 2), s));
   }
+  if (st.window_end()) FDTD_HIP_CHECK(hipEventRecord(st.window_end(), s));
   FDTD_HIP_CHECK(hipStreamSynchronize(s));
-
-  if (n_timed > 0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < n_timed; ++k) {
-      float ms0 = 0.f, ms1 = 0.f;
-      FDTD_HIP_CHECK(hipEventElapsedTime(&ms0, pool.ev[3 * k + 0], pool.ev[3 * k + 1]));
-      FDTD_HIP_CHECK(hipEventElapsedTime(&ms1, pool.ev[3 * k + 1], pool.ev[3 * k + 2]));
-      s0 += ms0;
-      s1 += ms1;
-    }
-    timers->section0 += s0 * 1e-3;
-    timers->section1 += s1 * 1e-3;
-  }
+  if (n_timed > 0) return st.finish(timers);
   return 0;
 }
 
