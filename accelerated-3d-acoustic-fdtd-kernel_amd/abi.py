@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfdtd_hip.so")
+    # FDTD_HIP_LIB: another build of the library (A/B measurements)
+    return os.environ.get("FDTD_HIP_LIB") or os.path.join(_HERE, "libfdtd_hip.so")
 
 
 class Dataobj(C.Structure):

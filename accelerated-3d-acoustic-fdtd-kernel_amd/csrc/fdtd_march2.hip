@@ -25,10 +25,11 @@
 // counted waits).  Memory is addressed with buffer instructions: descriptor (scalar) + plane
 // offset (scalar) + one loop-invariant 32-bit lane offset per row.
 //
-// Shapes: z extent a multiple of 512 cells with a y extent that is a multiple of 8, or z extent 256
-// with a y extent that is a multiple of 16 (the workgroup then carries two 8-row tiles, one per wave
-// parity); at most 8 sources; anything else is run as two single sweeps by fdtd_hip_two_steps.
-// Rows longer than 512 cells are cut into z-tiles of 512.  A tile cannot know its neighbour's C
+// Shapes: z extent a multiple of 512 cells with a y extent that is a multiple of 8, or z extent a
+// multiple of 256 with a y extent that is a multiple of 16 (the workgroup then carries two 8-row
+// tiles of 256-cell rows, one per wave parity); at most 8 sources; anything else is run as two
+// single sweeps by fdtd_hip_two_steps.
+// Longer rows are cut into z-tiles of 512 (or 256) cells.  A tile cannot know its neighbour's C
 // beyond the cut in time, so the four D cells around every cut (two on either side) come out wrong
 // and are recomputed by seam_kernel after the sweep, from the C level in memory; the second scatter
 // then runs as a launch of its own after that.
@@ -140,15 +141,15 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // ZH = 1: rows of 256 cells; the workgroup then carries two independent 8-row tiles stacked in y,
 // h selects the tile (each computes its own redundant rows; the LDS columns 0..63 / 64..127 are theirs).
 template <bool NT, int ZH>
-__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt) {
+__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt, int wg_base) {
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = wave & 1, q = wave >> 1;
-  const int t = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int yt = t % nyt, zt = (t / nyt) % nzt, xc = t / (nyt * nzt);
-  const int zb = a.z_m + zt * M2_ZCELLS;                // first cell of this z-tile
+  const int zb = a.z_m + zt * (ZH == 2 ? M2_ZCELLS : M2_ZCELLS / 2);   // first cell of this z-tile
   const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (2 * yt + h) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int hslot = q < 2 ? q : 12 + q;
   const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
   const int lz = ZH == 2 ? lc : lane;                   // float4 index inside the row of cells
-  const bool seam_lane = ZH == 2 && ((lc == 0 && zt > 0) || (lc == 127 && zt < nzt - 1));   // next to a z-cut
+  const bool seam_lane = (lz == 0 && zt > 0) || (lz == 64 * ZH - 1 && zt < nzt - 1);   // next to a z-cut
   // Addresses: descriptor base + scalar offset (plane + row, wave-uniform) + one lane offset along z.
   // vz: the lane's 4 cells; vze: the 2 cells before them, or behind them in the last lane; vzc: the
   // same for the C array, where only the two cells before lane 0 / behind lane 63 are ever used, so
@@ -410,12 +411,13 @@ struct SeamArgs {
   float *D;
   long sx;
   int sy, x_m, y_m, y_M, z_m;
+  int zstep;          // cells between cuts
   Coef2 k;
 };
 __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
   const int j = threadIdx.x & 1, y = a.y_m + (int)blockIdx.x * 128 + (int)(threadIdx.x >> 1);
   if (y > a.y_M) return;
-  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + ((int)blockIdx.y + 1) * M2_ZCELLS - 2 + 2 * j;
+  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + ((int)blockIdx.y + 1) * a.zstep - 2 + 2 * j;
   const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
   auto ld = [](const float *p, long at) { return *(const f32x2 *)(p + at); };
   const f32x2 c = ld(a.C, i), zm = ld(a.C, i - 2), zp = ld(a.C, i + 2);
@@ -487,9 +489,9 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
                           const float *c, const float *d, int nsrc) {
   if (!g) return false;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
-  // rows of k * 512 cells in tiles of 8 rows, or rows of 256 cells in pairs of such tiles
-  const int tile_rows = ez == M2_ZCELLS / 2 ? 2 * M2_ROWS : M2_ROWS;
-  if (ex < 1 || (ez % M2_ZCELLS && ez != M2_ZCELLS / 2) || ez < 1 || ey < tile_rows || ey % tile_rows) return false;
+  // rows of k * 512 cells in tiles of 8 rows, or rows of k * 256 cells in pairs of such tiles
+  const int tile_rows = ez % M2_ZCELLS ? 2 * M2_ROWS : M2_ROWS;
+  if (ex < 1 || ez % (M2_ZCELLS / 2) || ez < 1 || ey < tile_rows || ey % tile_rows) return false;
   if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
   if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
   if (((long)g->nyp * g->nzp) % 4) return false;
@@ -501,13 +503,15 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
   return true;
 }
 
-// Does the automatic choice take the fused kernel for an eligible problem?  Rows of k * 512 cells over
-// at least FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of
-// u(time+1) each chunk recomputes, and with rows of 256 cells the marching kernel was the faster one
-// where measured (256^3: 300 against 253 Gcells/s), so those are fused only on explicit request.
+// Does the automatic choice take the fused kernel for an eligible problem?  Rows of k * 512 cells,
+// or of k * 256 cells from 768 on, over at least FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges
+// spend too much on the four planes of u(time+1) each chunk recomputes, and a grid with rows of 256
+// cells sits in the last-level cache, where the marching kernel was the faster one (256^3: 300
+// against 253 Gcells/s), so that one is fused only on explicit request.
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
   const int ex = g->x_M - g->x_m + 1, ez = g->z_M - g->z_m + 1;
-  return ez % M2_ZCELLS == 0 && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
+  return (ez % M2_ZCELLS == 0 || (ez % (M2_ZCELLS / 2) == 0 && ez > M2_ZCELLS)) &&
+         ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 
 // Two steps (time, time + 1) on four level buffers: cur = u(time), prev = u(time-1) are read,
@@ -542,28 +546,40 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   const int own_hi = (g->x_M == dx_M ? g->x_M + 1 : g->x_M) + x_shift;
   const int gx_m = dx_m + x_shift, gx_M = dx_M + x_shift;
 
-  // Launch shape: one workgroup per CU (the LDS of a CU holds one tile), nyt y-tiles times as
-  // many x-chunks as fill 256 workgroups; long x ranges are cut into several launches so that
-  // workgroups march at most ~128 planes side by side (they drift apart beyond that and stop
-  // finding each other's rows in L2).
+  // Launch shape: one workgroup per CU at a time (the LDS of a CU holds one tile).  The x range is
+  // cut into chunks of at most ~128 planes (workgroups marching side by side drift apart beyond
+  // that and stop finding each other's rows in L2); every tile x chunk is a workgroup, and the
+  // device works through ceil(workgroups / 256) rounds of chunk length + lead-in.  The number of
+  // chunks is the one with the shortest total under that model.  Every round is a launch of its
+  // own: workgroups of one launch start together and stay in step with their y-neighbours, which
+  // is what makes one of two requests for a shared row hit in L2 (all rounds in one launch:
+  // 1024^3 at 372 instead of 437 Gcells/s).
   const int ez = g->z_M - g->z_m + 1;
-  const int tile_rows = ez == M2_ZCELLS / 2 ? 2 * M2_ROWS : M2_ROWS;
+  const bool wide = ez % M2_ZCELLS == 0;                     // z-tiles of 512 cells, else of 256
+  const int zstep = wide ? M2_ZCELLS : M2_ZCELLS / 2;
+  const int tile_rows = wide ? M2_ROWS : 2 * M2_ROWS;
   const int nyt = ey / tile_rows > 0 ? ey / tile_rows : 1;
-  const int nzt = ez >= M2_ZCELLS ? ez / M2_ZCELLS : 1;      // z-tiles of 512 cells
+  const int nzt = ez / zstep > 0 ? ez / zstep : 1;
   const int ntile = nyt * nzt;
-  const int nxc = ntile >= 256 ? 1 : (256 + ntile / 2) / ntile;
   // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
   const long plane_bytes = (long)g->nyp * g->nzp * 4;
   const long addressable = ((1L << 31) - 1) / plane_bytes - 9;
   int xchunk = env_int2("FDTD_FUSE2_XCHUNK", 0);
   if (xchunk <= 0) {
-    const int per_launch_cap = addressable < 128 ? (addressable > 1 ? (int)addressable : 1) : 128;
-    xchunk = (ex + nxc - 1) / nxc;
-    if (xchunk > per_launch_cap) {
-      const int launches = (ex + nxc * per_launch_cap - 1) / (nxc * per_launch_cap);
-      xchunk = (ex + nxc * launches - 1) / (nxc * launches);
+    const int longest = addressable < 128 ? (addressable > 1 ? (int)addressable : 1) : 128;
+    const int shortest = ex < 16 ? ex : 16;   // each chunk recomputes 4 planes of C
+    long best_cost = -1;
+    for (int c = (ex + longest - 1) / longest; c <= ex; ++c) {
+      const int len = (ex + c - 1) / c;
+      if (len < shortest) break;
+      const long rounds = ((long)ntile * ((ex + len - 1) / len) + 255) / 256;
+      const long cost = rounds * (len + 6);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        xchunk = len;
+      }
     }
-    if (xchunk < 16) xchunk = ex < 16 ? ex : 16;   // each chunk recomputes 4 planes of C
+    if (xchunk <= 0) xchunk = ex;
   }
   const bool offsets_ok = xchunk <= addressable;
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
@@ -655,27 +671,32 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.nsrc = nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride; a.x_shift = x_shift;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
   const bool nt = env_int2("FDTD_NT", 1) != 0;
-  // several launches of nxc chunks each
-  for (int x0 = g->x_m; x0 <= g->x_M; x0 += nxc * xchunk) {
-    March2Args al = a;
-    al.x_m = x0;
-    al.x_M = x0 + nxc * xchunk - 1 < g->x_M ? x0 + nxc * xchunk - 1 : g->x_M;
-    const int chunks = (al.x_M - al.x_m + xchunk) / xchunk;
-    const dim3 grid((unsigned)(ntile * chunks)), block(512);
-    if (ez >= M2_ZCELLS) {
-      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, al, xchunk, nyt, nzt);
-      else hipLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, al, xchunk, nyt, nzt);
-    } else {
-      if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, al, xchunk, nyt, 1);
-      else hipLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, al, xchunk, nyt, 1);
+  {
+    const long chunks = (ex + xchunk - 1) / xchunk;
+    if ((long)ntile * chunks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    const long total = (long)ntile * chunks;
+    // a cross-section of more than 256 tiles goes into one launch whole: with the tiles of one
+    // chunk spread over several launches the 256 x 2048 x 2048 slab ran at 323 instead of 371 Gcells/s
+    const int per_launch = env_int2("FDTD_FUSE2_WGS", ntile > 256 ? ntile : 256);
+    for (long base = 0; base < total; base += per_launch) {
+      const dim3 grid((unsigned)(total - base < per_launch ? total - base : per_launch)), block(512);
+      const int b = (int)base;
+      if (wide) {
+        if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
+        else hipLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
+      } else {
+        if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
+        else hipLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
+      }
+      __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
     }
-    __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
   }
   if (nzt > 1) {
     SeamArgs sa;
     sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2;
     sa.sx = a.sx; sa.sy = a.sy; sa.x_m = g->x_m; sa.y_m = g->y_m; sa.y_M = g->y_M; sa.z_m = g->z_m;
     sa.k = a.k;
+    sa.zstep = zstep;
     // grid.z is limited to 65535 planes
     for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
       sa.x_m = x0;

@@ -183,9 +183,10 @@ def main():
             fn = L.fdtd_hip_source_inject_h16 if h16 else L.fdtd_hip_source_inject
             return fn(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
 
-        # the library fuses rows of k * 512 cells by itself, rows of 256 cells only when asked to
+        # the library fuses rows of k * 512 cells (k * 256 from 768 on) by itself, rows of 256 cells only when asked to
         fused = ((not h16) and os.environ.get("FDTD_FUSE2", "1") != "0" and
-                 ((args.variant in ("auto", "march2") and n % 512 == 0) or (args.variant == "march2" and n == 256)))
+                 ((args.variant in ("auto", "march2") and (n % 512 == 0 or (n % 256 == 0 and n > 512))) or
+                  (args.variant == "march2" and n == 256)))
         updates_per_launch = 1
         if fused:
             # Two steps per sweep: four level buffers rotate (the three ring slots and one more).  All

@@ -161,16 +161,15 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * nxp*nyp*nzp floats each: cur = u(time) and prev = u(time-1) are read, next1 =
  * u(time+1) and next2 = u(time+2) are written (interior cells only; the halo cells of
  * next1 and next2 keep their values and are read as such).  Both source scatters are
- * included.  When the shape allows (z extent a multiple of 512, y extent a multiple of 8, at most 8
- * sources) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
+ * included.  When the shape allows (z extent a multiple of 512 and y extent a multiple of 8, or z
+ * extent a multiple of 256 and y extent a multiple of 16; at most 8 sources) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
  * per cell update; otherwise they run one after the other.  Either way the result is
  * bit for bit that of two single steps.  This is the time fusion the reference driver
  * has a knob for (t_fuse, main.cpp:261,267) and no reference kernel implements.
  * next2 must not alias prev.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
  * the fusion, any other variant selects the single-step kernel used for both sweeps.
- * FDTD_VARIANT_MARCH2 fuses regardless of the x range and also takes a z extent of 256
- * with a y extent that is a multiple of 16 (AUTO leaves those to the single-step kernel,
- * which is faster there). */
+ * FDTD_VARIANT_MARCH2 fuses regardless of the x range and also at a z extent of exactly
+ * 256 (AUTO leaves that one to the single-step kernel, which is faster there). */
 int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
                        const float *src_coords, const float *cur, const float *prev,
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,
