@@ -533,6 +533,13 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
                         int variant, int flags, int x_shift, int global_nx, void *stream, hipEvent_t ev_begin,
                         hipEvent_t ev_end, float *scratch, long scratch_floats) {
   if (!g || !m || !cur || !prev || !next1 || !next2) return (int)hipErrorInvalidValue;
+  {  // the two written levels must not overlap each other or anything that is read
+    const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
+    auto overlap = [vol](const float *a, const float *b) { return a < b + vol && b < a + vol; };
+    if (overlap(next1, next2) || overlap(next1, cur) || overlap(next1, prev) || overlap(next1, m) ||
+        overlap(next2, cur) || overlap(next2, prev) || overlap(next2, m))
+      return (int)hipErrorInvalidValue;
+  }
   const bool has_src = p_src_M >= p_src_m;
   if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
   const int nsrc = has_src ? p_src_M - p_src_m + 1 : 0;

@@ -166,7 +166,9 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * per cell update; otherwise they run one after the other.  Either way the result is
  * bit for bit that of two single steps.  This is the time fusion the reference driver
  * has a knob for (t_fuse, main.cpp:261,267) and no reference kernel implements.
- * next2 must not alias prev.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
+ * next1 and next2 must not overlap each other, cur, prev or m (refused with
+ * hipErrorInvalidValue): unlike the reference's ring, u(time+2) cannot be written over
+ * u(time-1), because neighbouring workgroups still read it.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
  * the fusion, any other variant selects the single-step kernel used for both sweeps.
  * FDTD_VARIANT_MARCH2 fuses regardless of the x range and also at a z extent of exactly
  * 256 (AUTO leaves that one to the single-step kernel, which is faster there). */

@@ -316,6 +316,30 @@ def test_small_grid_time_loop(pkg, hiplib, name):
     assert (prof.section0 > 0) == (n_steps > pkg.WARMUP_STEPS)
 
 
+def test_two_steps_rejects_overlapping_levels(pkg, hiplib):
+    """fdtd_hip_two_steps writes two levels while it reads two others: any overlap between a written
+    level and another argument is refused (hipErrorInvalidValue = 1), nothing is launched."""
+    import torch
+    n = (20, 16, 512)
+    pshape = tuple(v + 8 for v in n)
+    buf = torch.zeros((5,) + pshape, device="cuda")
+    m = torch.full(pshape, 1.5, device="cuda")
+    g = pkg.Geom(*pshape, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+    P = [buf[i].data_ptr() for i in range(5)]
+
+    def call(cur, prev, n1, n2):
+        return hiplib.fdtd_hip_two_steps(C.byref(g), m.data_ptr(), None, None, cur, prev, n1, n2, 0, 0, -1, 1, 3,
+                                         pkg.VARIANTS["auto"], None)
+
+    assert call(P[0], P[1], P[2], P[3]) == 0
+    assert call(P[0], P[1], P[2], P[2]) == 1      # both results in one buffer
+    assert call(P[0], P[1], P[2], P[1]) == 1      # u(t+2) over u(t-1): the reference's ring, not possible here
+    assert call(P[0], P[1], P[0], P[3]) == 1
+    assert call(P[0], P[1], P[2], P[2] + 4096) == 1   # partial overlap
+    assert call(P[0], P[1], m.data_ptr(), P[3]) == 1
+    torch.cuda.synchronize()
+
+
 def test_t_fuse_knob_requests_fused_sweep(pkg, hiplib):
     """FDTD_SetRuntimeConfig(use_tc, t_fuse, nfields), the driver's hook (main.cpp:84,272): with
     t_fuse = 2 the optimized operator fuses even an x range of 20 planes, with 1 it does not; both
