@@ -367,8 +367,8 @@ class HipStepper:
         self.ev_interior = None
         self.pending = []           # message requests the next boundary update waits for
         # Two steps per exchange only: the interior sweep also waits for the previous messages.  It
-        # does not need them, but RCCL's waves do not fit next to the fused sweep's (136 + 2 x 216
-        # registers per SIMD lane), so messages issued while a sweep runs complete when it drains; if
+        # does not need them, but RCCL's waves do not fit next to the fused sweep's (264 + 2 x 208
+        # registers per SIMD lane of 512), so messages issued while a sweep runs complete when it drains; if
         # the next sweep started before that, the boundary zone would fall a whole sweep behind and
         # stay there (its result is what the sweep after needs).
         self.hold_interior = False
