@@ -70,6 +70,7 @@ struct March2Args {
   int nsrc, p_src_m, coord_stride;
   int z_M;
   int scatter_d;      // 0: the second scatter is left to the caller (rows cut into z-tiles)
+  int keep_lo, keep_hi;   // store C on the two planes before x_m / behind x_M as well (inside the domain)
   int x_shift;        // source positions are in the coordinates of the whole domain: plane = position - x_shift
   float h_x, h_y, h_z, o_x, o_y, o_z;
 };
@@ -285,7 +286,9 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     const bool more = STEADY ? true : p < p_last;
     const int sq = sp + (more ? sxb : 0);   // plane p+1 (repeats plane p at the very end)
     const bool plane_inside = STEADY ? true : (p >= a.dx_m && p <= a.dx_M);
-    const bool store_c = STEADY ? true : (plane_inside && p >= x_begin && p <= x_end);
+    const bool store_c = STEADY ? true
+                                : (plane_inside && ((p >= x_begin && p <= x_end) || (a.keep_lo && p < a.x_m) ||
+                                                    (a.keep_hi && p > a.x_M)));
     const int d = p - 2;
     const bool do_d = STEADY ? true : (d >= x_begin && d <= x_end);
     const unsigned long cmask = __ballot(cvalid && cx == p);       // corners of the first scatter in plane p
@@ -520,7 +523,8 @@ bool fdtd_march2_preferred(const struct fdtd_geom *g) {
 // two sweeps; the result is the same bit for bit.
 // ev_begin / ev_end, when not null, are recorded right before the first and right after the last
 // sweep kernel.  flags bit 0: the caller guarantees that no source corner lands in the halo layer
-// (the two small launches that serve such corners are skipped).
+// (the two small launches that serve such corners are skipped); bits 2 and 3: u(time+1) is stored
+// on the two planes before x_m / behind x_M too, where those are inside the domain.
 //
 // Slab form (global_nx > 0): the arrays hold planes x_shift-4 .. of a domain of global_nx planes,
 // g->x_m..x_M is the local range to update, source positions are global.  u(time+1) is needed two
@@ -627,8 +631,11 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     }
     rc = fdtd_stencil_levels(g, m, c_lvl, cur, next2, v1, stream);
     if (rc) return rc;
-    FDTD_HIP_CHECK(hipMemcpyAsync(next1 + (long)(g->x_m + FDTD_HALO) * plane, scratch + 2 * plane,
-                                  (size_t)ex * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // back into next1: the range, and on request the extra planes the caller has no other source for
+    const int back_lo = (flags & 4) ? g1.x_m : g->x_m, back_hi = (flags & 8) ? g1.x_M : g->x_M;
+    FDTD_HIP_CHECK(hipMemcpyAsync(next1 + (long)(back_lo + FDTD_HALO) * plane,
+                                  scratch + (long)(back_lo - (g->x_m - 2)) * plane,
+                                  (size_t)(back_hi - back_lo + 1) * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
     if (has_src)
       rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
@@ -665,6 +672,8 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.x_m = g->x_m; a.x_M = g->x_M; a.dx_m = dx_m; a.dx_M = dx_M;
   a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.scatter_d = nzt == 1;
+  a.keep_lo = (flags & 4) != 0;
+  a.keep_hi = (flags & 8) != 0;
   a.k.cm2 = -8.33333333e-2F; a.k.cm1 = 1.333333330F; a.k.c0 = -2.50F;
   a.k.dt2 = g->dt * g->dt;
   a.k.r1 = 1.0F / (g->dt * g->dt);

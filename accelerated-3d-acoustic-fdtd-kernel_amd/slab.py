@@ -209,9 +209,9 @@ class SlabPairPropagator:
     `levels` are four tensors [nx_loc+8][nyp][nzp]: the three ring slots as they stand at `time0`
     (slot i holds what level i of a [3][...] array holds) and one spare.  The 4-plane padding in
     x is the ghost zone: a pair of steps reads u(t) four planes and u(t-1) two planes beyond the
-    owned range and recomputes u(t+1) on two ghost planes, bit for bit as the neighbour does.
-    After a pair the outermost 4 owned planes of u(t+2) and 2 of u(t+1) go to each neighbour; after
-    a single step (odd counts) the outermost 4 planes of the new level.  The schedule is the
+    owned range and recomputes u(t+1) on two ghost planes, bit for bit as the neighbour does (and
+    keeps them: the next pair reads them as its u(t-1)).  After a pair the outermost 4 owned planes
+    of u(t+2) go to each neighbour; after a single step (odd counts) those of the new level.  The schedule is the
     two-chain one of SlabPropagator with a boundary zone of 4 planes.
 
     In the reference's ring a level inherits the halo of the slot it overwrites (u(t+2) that of
@@ -254,7 +254,8 @@ class SlabPairPropagator:
             if not boundary:
                 st.interior_done()
         st.boundary_done()
-        self.comm.exchange_planes(self, [(self.spare, PAIR_GHOST), (self.third, GHOST)])
+        # u(t+1) needs no message: its two ghost planes were computed here, as the neighbour computes them
+        self.comm.exchange_planes(self, [(self.spare, PAIR_GHOST)])
         self.cur, self.prev, self.third, self.spare = self.spare, self.third, self.cur, self.prev
 
     def single(self, time):
@@ -506,7 +507,8 @@ class HipStepper:
         rc = self.lib.fdtd_hip_two_steps_slab(
             C.byref(self._range_geom(x_lo, x_hi)), self.m_ptr, self.src_ptr, self.coords_ptr, self.lv_ptr[cur],
             self.lv_ptr[prev], self.lv_ptr[n1], self.lv_ptr[n2], time, 0, p.nsrc - 1, self.src_stride,
-            self.coord_stride, variant, self.flags, p.x_off, p.layout.NX,
+            self.coord_stride, variant, self.flags | (4 if x_lo == 0 else 0) | (8 if x_hi == p.nx - 1 else 0),
+            p.x_off, p.layout.NX,
             self.scratch.data_ptr() if (boundary and self.scratch is not None) else None,
             self.scratch.numel() if (boundary and self.scratch is not None) else 0, self._sh[boundary])
         if rc:

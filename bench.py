@@ -282,7 +282,7 @@ def main():
             "workload": (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
                          f"{total_steps} steps ({W} untimed)" if not slabs else
                          f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, "
-                         + ("two steps per sweep and exchange (4 + 2 ghost planes per side)" if updates_per_launch == 2
+                         + ("two steps per sweep and exchange (4 ghost planes of u(t+2) per side)" if updates_per_launch == 2
                             else "2-plane ghost exchange per step")
                          + f" over {'RCCL' if os.environ.get('FDTD_BENCH_BACKEND', 'nccl') == 'nccl' else 'gloo (host-staged rehearsal)'}"
                          + f", {total_steps} steps ({W} untimed)"),

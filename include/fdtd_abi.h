@@ -211,7 +211,13 @@ int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float
  * nothing outside the range, which is what a range needs that is updated while its
  * neighbouring ranges are (the boundary zone of a slab); without scratch (NULL) the first of
  * the two sweeps stores u(time+1) on the extra planes of next1 too (same values as their owner
- * stores), so such calls must not run concurrently with calls on adjacent ranges. */
+ * stores), so such calls must not run concurrently with calls on adjacent ranges.
+ * flags: FDTD_TWO_STEPS_SOURCES_INSIDE as above; FDTD_TWO_STEPS_KEEP_LOW / _KEEP_HIGH make
+ * every path store u(time+1) on the two planes before x_m / behind x_M (where the domain
+ * has them).  A slab sets them on the side of a neighbour: its ghost planes of u(time+1),
+ * which the next pair reads as u(t-1), are then computed here and need not be sent. */
+#define FDTD_TWO_STEPS_KEEP_LOW 4
+#define FDTD_TWO_STEPS_KEEP_HIGH 8
 int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m, const float *src,
                             const float *src_coords, const float *cur, const float *prev,
                             float *next1, float *next2, int time, int p_src_m, int p_src_M,

@@ -112,7 +112,7 @@ def test_slab_rccl_schedule_one_gpu(pkg, tmp_path, name, march):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["fused_z512", "fused_z512_edge_source", "fused_z512_ricker8", "fused_z1024"])
 def test_slab_pairs_rccl_schedule_one_gpu(pkg, tmp_path, name):
-    """Two steps per exchange with real RCCL messages (4 + 2 planes per side and pair) next to the fused
+    """Two steps per exchange with real RCCL messages (4 planes per side and pair) next to the fused
     interior sweep, one rank as its own two neighbours; bit-identical to the CPU orchestration."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
