@@ -226,14 +226,14 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((48, 64, 256), 2, "march2"), ((300, 256, 256), 1, "march2"),
                                                 ((24, 8, 512), 0, "march2"), ((520, 512, 512), 1, "auto"),
                                                 ((20, 16, 1024), 3, "march2"), ((70, 24, 1536), 2, "auto"),
-                                                ((40, 32, 768), 2, "auto")])
+                                                ((40, 32, 768), 2, "auto"), ((300, 1024, 1024), 2, "auto")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
     one launch, forced fusion on a short x range, rows of 256 cells (fused on request only), no
     sources, an x range long enough to be cut into two launches (520 planes at 64 y-tiles), and rows
     of 1024, 1536 and 768 cells (two and three z-tiles of 512, three of 256; the cells around the cuts
-    are redone by the seam pass)."""
+    are redone by the seam pass); the last shape is a full cross-section of 256 tiles in three launches."""
     import torch
     nx, ny, nz = shape
     gen = torch.Generator(device="cuda").manual_seed(1234)
