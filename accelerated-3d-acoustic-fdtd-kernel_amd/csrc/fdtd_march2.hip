@@ -591,6 +591,16 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       }
     }
     if (xchunk <= 0) xchunk = ex;
+    // flags bits 8..15: make the last chunk that many planes shorter than the others (one round of
+    // several chunks only).  Its workgroups then finish early, and a kernel that cannot be placed
+    // beside this one (RCCL's send/receive kernel, which needs more than half of a SIMD's
+    // registers per wave) gets their CUs while the other chunks are still running.
+    const int tail = (flags >> 8) & 0xff;
+    const int chunks = (ex + xchunk - 1) / xchunk;
+    if (tail > 0 && chunks >= 2 && (long)ntile * chunks <= 256) {
+      const int longer = (ex + tail + chunks - 1) / chunks;
+      if (longer <= longest && ex - (chunks - 1) * longer >= shortest) xchunk = longer;
+    }
   }
   const bool offsets_ok = xchunk <= addressable;
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&

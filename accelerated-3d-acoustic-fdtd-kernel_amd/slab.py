@@ -25,6 +25,7 @@ run.  What is new is the data movement:
 orchestration with a CPU stepper built on the oracle).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -471,6 +472,10 @@ class HipStepper:
         self.split = prop.overlap
         self._sh = {True: C.c_void_p(self.edge.cuda_stream), False: C.c_void_p(self.inner.cuda_stream)}
         self.flags = 1 if prop.uniform_halos else 0
+        # The message kernel cannot be placed beside the interior sweep; a shorter last x-chunk ends
+        # early and hands it CUs for the tail of the sweep (FDTD_SLAB_TAIL_PLANES, 0 = equal chunks).
+        # 24 planes are about 115 us at a 512 x 512 cross-section; the sweep as a whole is no slower.
+        self.tail_planes = max(0, min(255, int(os.environ.get("FDTD_SLAB_TAIL_PLANES", "24"))))
         self.hold_interior = True
         # the boundary zones are updated next to the interior: their u(t+1) planes are built in scratch
         self.scratch = None
@@ -507,7 +512,9 @@ class HipStepper:
         rc = self.lib.fdtd_hip_two_steps_slab(
             C.byref(self._range_geom(x_lo, x_hi)), self.m_ptr, self.src_ptr, self.coords_ptr, self.lv_ptr[cur],
             self.lv_ptr[prev], self.lv_ptr[n1], self.lv_ptr[n2], time, 0, p.nsrc - 1, self.src_stride,
-            self.coord_stride, variant, self.flags | (4 if x_lo == 0 else 0) | (8 if x_hi == p.nx - 1 else 0),
+            self.coord_stride, variant,
+            self.flags | (4 if x_lo == 0 else 0) | (8 if x_hi == p.nx - 1 else 0)
+            | ((self.tail_planes << 8) if (self.split and not boundary) else 0),
             p.x_off, p.layout.NX,
             self.scratch.data_ptr() if (boundary and self.scratch is not None) else None,
             self.scratch.numel() if (boundary and self.scratch is not None) else 0, self._sh[boundary])

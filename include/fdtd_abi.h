@@ -218,6 +218,10 @@ int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float
  * which the next pair reads as u(t-1), are then computed here and need not be sent. */
 #define FDTD_TWO_STEPS_KEEP_LOW 4
 #define FDTD_TWO_STEPS_KEEP_HIGH 8
+/* flags bits 8..15: n > 0 makes the last x-chunk of the fused sweep n planes shorter than the
+ * others, so that its workgroups end early and free their CUs for a kernel that cannot run
+ * beside the sweep (the message kernel of the ghost exchange); results do not depend on it. */
+#define FDTD_TWO_STEPS_TAIL(n) (((n) & 0xff) << 8)
 int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m, const float *src,
                             const float *src_coords, const float *cur, const float *prev,
                             float *next1, float *next2, int time, int p_src_m, int p_src_M,
