@@ -477,9 +477,16 @@ class HipStepper:
         # 24 planes are about 115 us at a 512 x 512 cross-section; the sweep as a whole is no slower.
         self.tail_planes = max(0, min(255, int(os.environ.get("FDTD_SLAB_TAIL_PLANES", "24"))))
         self.hold_interior = True
-        # the boundary zones are updated next to the interior: their u(t+1) planes are built in scratch
+        # The boundary zones are updated next to the interior.  Small cross-sections: two small sweeps
+        # with their u(t+1) planes built in scratch, which run in the registers and LDS the interior
+        # sweep leaves free.  From 256 tiles of the fused sweep on (1024 x 1024 cells) those small
+        # sweeps are starved for so long that the fused sweep itself, which stores nothing outside
+        # its range either, is the cheaper way (FDTD_SLAB_ZONE_FUSED=0/1 overrides).
+        tiles = ((nyp - 2 * HALO) // 8) * ((nzp - 2 * HALO) // 512)
+        zf = os.environ.get("FDTD_SLAB_ZONE_FUSED")
+        self.zone_fused = prop.overlap and (tiles >= 256 if zf is None else zf != "0")
         self.scratch = None
-        if prop.overlap:
+        if prop.overlap and not self.zone_fused:
             self.scratch = self.torch.empty((PAIR_GHOST + 4, nyp, nzp), dtype=self.torch.float32, device=self.device)
 
     def _range_geom(self, x_lo, x_hi):
@@ -508,7 +515,7 @@ class HipStepper:
         ev = self._timed(boundary, stream)
         # Side by side with the boundary zones the interior has to be the fused sweep whatever its
         # length (it stores nothing outside its range); the zones themselves go through scratch.
-        variant = abi.VARIANTS["march2"] if (self.split and not boundary) else self.variant
+        variant = abi.VARIANTS["march2"] if (self.split and (not boundary or self.zone_fused)) else self.variant
         rc = self.lib.fdtd_hip_two_steps_slab(
             C.byref(self._range_geom(x_lo, x_hi)), self.m_ptr, self.src_ptr, self.coords_ptr, self.lv_ptr[cur],
             self.lv_ptr[prev], self.lv_ptr[n1], self.lv_ptr[n2], time, 0, p.nsrc - 1, self.src_stride,

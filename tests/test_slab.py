@@ -110,12 +110,17 @@ def test_slab_rccl_schedule_one_gpu(pkg, tmp_path, name, march):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["fused_z512", "fused_z512_edge_source", "fused_z512_ricker8", "fused_z1024"])
-def test_slab_pairs_rccl_schedule_one_gpu(pkg, tmp_path, name):
+@pytest.mark.parametrize("name,zone_fused", [("fused_z512", "0"), ("fused_z512_edge_source", "0"),
+                                             ("fused_z512_ricker8", "0"), ("fused_z1024", "0"),
+                                             ("fused_z512_edge_source", "1"), ("fused_z1024", "1")])
+def test_slab_pairs_rccl_schedule_one_gpu(pkg, tmp_path, name, zone_fused):
     """Two steps per exchange with real RCCL messages (4 planes per side and pair) next to the fused
-    interior sweep, one rank as its own two neighbours; bit-identical to the CPU orchestration."""
+    interior sweep, one rank as its own two neighbours; bit-identical to the CPU orchestration.  The
+    boundary zones go through the two small sweeps in scratch, or (as large cross-sections do by
+    default) through the fused sweep themselves."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
-               OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+               OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8",
+               FDTD_SLAB_ZONE_FUSED=zone_fused)
     p = subprocess.run([sys.executable, os.path.join(HERE, "slab_worker.py"), "nccl_self_pair", name, str(tmp_path)],
                        env=env, timeout=300)
     assert p.returncode == 0
