@@ -237,9 +237,12 @@ class SlabPairPropagator:
         exchanging = layout.world > 1 or getattr(comm, "has_neighbours", False)
         self.overlap = exchanging and self.nx >= 2 * PAIR_GHOST + 1 and stepper.pairs_can_overlap(self)
         stepper.bind_pairs(self)
+        self.edges_first = self.overlap and getattr(stepper, "zone_fused", False) and self.nx >= 3 * PAIR_GHOST
 
     def _ranges(self):
         nx, gw = self.nx, PAIR_GHOST
+        if self.overlap and self.edges_first:
+            gw = max(PAIR_GHOST, min(nx // 3, 96))
         if self.overlap:
             return [(gw, nx - gw - 1, False), (0, gw - 1, True), (nx - gw, nx - 1, True)]
         return [(0, nx - 1, True)]
@@ -250,13 +253,27 @@ class SlabPairPropagator:
         st.begin_step()
         if not self.uniform_halos:
             st.copy_shell(self.spare, self.prev)
-        for lo, hi, boundary in self._ranges():
+        ranges = self._ranges()
+        if self.overlap and self.edges_first:
+            # Large cross-sections: the outer thirds of the slab (ordinary x-chunks of the fused sweep,
+            # no extra lead-in planes) first, the messages as soon as those are done, the middle third
+            # behind them; a sweep of several rounds of workgroups leaves RCCL's kernel room by itself.
+            for lo, hi, boundary in ranges[1:]:
+                st.two_steps(lo, hi, self.cur, self.prev, self.third, self.spare, time, boundary)
+            st.boundary_done()
+            self.comm.exchange_planes(self, [(self.spare, PAIR_GHOST)])
+            st.interior_after_boundary()
+            lo, hi, boundary = ranges[0]
             st.two_steps(lo, hi, self.cur, self.prev, self.third, self.spare, time, boundary)
-            if not boundary:
-                st.interior_done()
-        st.boundary_done()
-        # u(t+1) needs no message: its two ghost planes were computed here, as the neighbour computes them
-        self.comm.exchange_planes(self, [(self.spare, PAIR_GHOST)])
+            st.interior_done()
+        else:
+            for lo, hi, boundary in ranges:
+                st.two_steps(lo, hi, self.cur, self.prev, self.third, self.spare, time, boundary)
+                if not boundary:
+                    st.interior_done()
+            st.boundary_done()
+            # u(t+1) needs no message: its two ghost planes were computed here, as the neighbour computes them
+            self.comm.exchange_planes(self, [(self.spare, PAIR_GHOST)])
         self.cur, self.prev, self.third, self.spare = self.spare, self.third, self.cur, self.prev
 
     def single(self, time):
@@ -300,8 +317,8 @@ class SlabPairPropagator:
 
     def interior_cells(self):
         nyp, nzp = self.levels[0].shape[1], self.levels[0].shape[2]
-        planes = self.nx - 2 * PAIR_GHOST if self.overlap else self.nx
-        return float(planes) * (nyp - 2 * HALO) * (nzp - 2 * HALO)
+        lo, hi, _ = self._ranges()[0]
+        return float(hi - lo + 1) * (nyp - 2 * HALO) * (nzp - 2 * HALO)
 
     def mean_interior_kernel_ms(self):
         return self.stepper.mean_interior_kernel_ms()
@@ -557,6 +574,11 @@ class HipStepper:
     def interior_done(self):
         self.ev_interior = self.torch.cuda.Event()
         self.ev_interior.record(self.inner)
+
+    def interior_after_boundary(self):
+        """Orders the interior call of this pair behind its boundary calls (same pair)."""
+        if self.split and self.ev_boundary is not None:
+            self.inner.wait_event(self.ev_boundary)
 
     def finish(self):
         self.begin_step()
