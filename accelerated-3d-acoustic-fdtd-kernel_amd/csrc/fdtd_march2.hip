@@ -408,7 +408,10 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
 
 // D on the four cells around every z-cut of the sweep above (cells cut-2 .. cut+1), from the C
 // level in memory once the sweep has completed it: same expression, same operand order.  One
-// thread per pair of cells; 128 rows x 2 pairs per workgroup, grid (row groups, cuts, planes).
+// thread per (row, cut, plane) computes the four cells as two pairs; the four cells start 8 bytes
+// off a 16-byte boundary, which a 16-byte global access tolerates (4-byte alignment is enough).
+// 256 rows per workgroup, grid (row groups, cuts, planes).  (A version that marched along x with
+// the centre row in registers moved half the bytes and was no faster: the accesses are 8 KB apart.)
 struct SeamArgs {
   const float *C, *B, *m;
   float *D;
@@ -417,18 +420,31 @@ struct SeamArgs {
   int zstep;          // cells between cuts
   Coef2 k;
 };
+struct __attribute__((packed, aligned(4))) Quad { float v[4]; };
 __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
-  const int j = threadIdx.x & 1, y = a.y_m + (int)blockIdx.x * 128 + (int)(threadIdx.x >> 1);
+  const int y = a.y_m + (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (y > a.y_M) return;
-  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + ((int)blockIdx.y + 1) * a.zstep - 2 + 2 * j;
+  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + ((int)blockIdx.y + 1) * a.zstep - 2;
   const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
-  auto ld = [](const float *p, long at) { return *(const f32x2 *)(p + at); };
-  const f32x2 c = ld(a.C, i), zm = ld(a.C, i - 2), zp = ld(a.C, i + 2);
-  const f32x2 zs2 = zm + zp, zs1 = f32x2{zm.y + c.y, c.x + zp.x};
-  const f32x2 o = update_pair(a.k, c, ld(a.C, i - 2 * a.sx), ld(a.C, i - a.sx), ld(a.C, i + a.sx), ld(a.C, i + 2 * a.sx),
-                              ld(a.C, i - 2 * a.sy), ld(a.C, i - a.sy), ld(a.C, i + a.sy), ld(a.C, i + 2 * a.sy), zs2, zs1,
-                              ld(a.B, i), ld(a.m, i));
-  *(f32x2 *)(a.D + i) = o;
+  auto ld = [](const float *p, long at) {
+    const Quad q = *(const Quad *)(p + at);
+    return f32x4{q.v[0], q.v[1], q.v[2], q.v[3]};
+  };
+  const f32x4 c = ld(a.C, i);
+  const f32x2 zm = *(const f32x2 *)(a.C + i - 2), zp = *(const f32x2 *)(a.C + i + 4);
+  const f32x4 xm2 = ld(a.C, i - 2 * a.sx), xm1 = ld(a.C, i - a.sx), xp1 = ld(a.C, i + a.sx), xp2 = ld(a.C, i + 2 * a.sx);
+  const f32x4 ym2 = ld(a.C, i - 2 * a.sy), ym1 = ld(a.C, i - a.sy), yp1 = ld(a.C, i + a.sy), yp2 = ld(a.C, i + 2 * a.sy);
+  const f32x4 up = ld(a.B, i), mc = ld(a.m, i);
+  const f32x2 cl = lo2(c), ch = hi2(c);
+  // cells 0,1: z-2: zm  z+2: ch   z-1: (zm.y, c.x)  z+1: (c.y, c.z)
+  // cells 2,3: z-2: cl  z+2: zp   z-1: (c.y, c.z)   z+1: (c.w, zp.x)
+  const f32x2 o0 = update_pair(a.k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1), lo2(yp2),
+                               zm + ch, f32x2{zm.y + c.y, c.x + c.z}, lo2(up), lo2(mc));
+  const f32x2 o1 = update_pair(a.k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1), hi2(yp2),
+                               cl + zp, f32x2{c.y + c.w, c.z + zp.x}, hi2(up), hi2(mc));
+  Quad o;
+  o.v[0] = o0.x; o.v[1] = o0.y; o.v[2] = o1.x; o.v[3] = o1.y;
+  *(Quad *)(a.D + i) = o;
 }
 
 // The shell: the two layers of cells around the updated box, i.e. every halo cell a sweep can
@@ -727,7 +743,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
       sa.x_m = x0;
       const int planes = g->x_M - x0 + 1 < 65535 ? g->x_M - x0 + 1 : 65535;
-      hipLaunchKernelGGL(seam_kernel, dim3((unsigned)((ey + 127) / 128), (unsigned)(nzt - 1), (unsigned)planes),
+      hipLaunchKernelGGL(seam_kernel, dim3((unsigned)((ey + 255) / 256), (unsigned)(nzt - 1), (unsigned)planes),
                          dim3(256), 0, s, sa);
     }
   }
