@@ -70,6 +70,11 @@ class OraclePairStepper:
     def __init__(self, U):
         import oracle_binding as ob
         self.ob, self.U = ob, U.numpy()
+        # FDTD_TEST_EDGES_FIRST=1: the schedule of large cross-sections (outer thirds, messages, middle third)
+        self.zone_fused = os.environ.get("FDTD_TEST_EDGES_FIRST") == "1"
+
+    def interior_after_boundary(self):
+        pass
 
     def pairs_can_overlap(self, prop):
         return True          # sequential here, so the three ranges of the two-chain schedule are exercised

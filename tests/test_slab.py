@@ -77,6 +77,16 @@ def test_slab_pairs_orchestration_cpu(pkg, tmp_path, name, world):
     check_against_golden(name, u, exact=True)
 
 
+@pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("noncubic_aniso", 2), ("time_offset", 2),
+                                        ("no_sources_random", 2)])
+def test_slab_pairs_edges_first_orchestration_cpu(pkg, tmp_path, name, world, monkeypatch):
+    """The pair schedule of large cross-sections (outer thirds of the slab first, then the messages, then
+    the middle third) over gloo with the oracle's sweeps: same bytes as the single-domain fixtures."""
+    monkeypatch.setenv("FDTD_TEST_EDGES_FIRST", "1")
+    u = run_slabs("oracle_pair", name, world, tmp_path, pkg)
+    check_against_golden(name, u, exact=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world", [("fused_z512", 2), ("fused_z512_edge_source", 2), ("fused_z512_ricker8", 3),
                                         ("ricker27_n32", 2), ("fused_z1024", 2)])
