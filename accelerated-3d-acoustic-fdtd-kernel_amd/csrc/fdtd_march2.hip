@@ -149,7 +149,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = wave & 1, q = wave >> 1;
   const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
-  const int yt = t % nyt, zt = (t / nyt) % nzt, xc = t / (nyt * nzt);
+  // z-tile fastest: the tiles on either side of a z-cut read each other's edge cells and should share an L2
+  const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
   const int zb = a.z_m + zt * (ZH == 2 ? M2_ZCELLS : M2_ZCELLS / 2);   // first cell of this z-tile
   const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (2 * yt + h) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
