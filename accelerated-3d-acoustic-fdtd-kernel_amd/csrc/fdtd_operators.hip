@@ -322,9 +322,11 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
   }
   if (variant == FDTD_VARIANT_MARCH2) variant = FDTD_VARIANT_AUTO;
 
-  // small grids: one launch per step
-  if (!h16 && variant == FDTD_VARIANT_AUTO && time_M >= time_m && g->x_M >= g->x_m && g->y_M >= g->y_m &&
-      g->z_M >= g->z_m && fdtd_auto_is_naive(g, m, (const float *)u)) {
+  // small grids (automatic choice, or the one-cell-per-thread kernel asked for by name): one launch per step
+  const bool small_naive = variant == FDTD_VARIANT_NAIVE &&
+                           (long)(g->x_M - g->x_m + 1) * (g->y_M - g->y_m + 1) * (g->z_M - g->z_m + 1) < 6000000L;
+  if (!h16 && time_M >= time_m && g->x_M >= g->x_m && g->y_M >= g->y_m && g->z_M >= g->z_m &&
+      (small_naive || (variant == FDTD_VARIANT_AUTO && fdtd_auto_is_naive(g, m, (const float *)u)))) {
     const char *e = getenv("FDTD_SMALL_FUSED");
     if (!e || atoi(e) != 0) {
       const int rc = time_loop_small(g, m, src, src_coords, (float *)u, p_src_m, p_src_M, src_stride, coord_stride,
