@@ -201,20 +201,26 @@ def main():
                                            P[third].data_ptr(), t, 0, 0, 1, 3, variant, sh) == 0
                 cur, prev, third = third, cur, prev
             n_pairs = K // 2
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pairs)]
-            for a, b in ev:          # torch creates the HIP event at the first record; the library re-records it
+            # Every two-step call hands the library two events.  Where the call is a single sweep launch
+            # (512-wide rows) they receive the start and stop times of that dispatch itself, which is the
+            # kernel duration a profiler reports; otherwise they are recorded on the stream around all the
+            # launches of the call (sweep launches, seam pass, scatter).
+            stride = 1
+            ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for i in range(0, n_pairs, stride)}
+            for a, b in ev.values():  # torch creates the HIP event at the first record; the library re-records it
                 a.record(stream)
                 b.record(stream)
-            evh = [(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)) for a, b in ev]
+            evh = {i: (C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)) for i, (a, b) in ev.items()}
             torch.cuda.synchronize()
             t_start = time.perf_counter()
             t = W
             for i in range(n_pairs):
-                # One event after every sweep kernel (and one before the first): consecutive events are one
-                # launch apart.  The source is inside the grid (flag 1: no halo-corner launches).
+                # The source is inside the grid (flag 1: no halo-corner launches).
+                h = evh.get(i, (None, None)) if os.environ.get("FDTD_BENCH_EVENTS", "1") != "0" else (None, None)
                 rc = L.fdtd_hip_two_steps_ex(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
                                              P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, variant, 1,
-                                             evh[i][0] if i == 0 else None, evh[i][1], sh)
+                                             h[0], h[1], sh)
                 assert rc == 0, rc
                 cur, prev, third, spare = spare, third, cur, prev
                 t += 2
@@ -224,7 +230,10 @@ def main():
                 cur, prev, third = third, cur, prev
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t_start
-            kernel_ms = ev[0][0].elapsed_time(ev[-1][1]) / n_pairs
+            if os.environ.get("FDTD_BENCH_EVENTS", "1") != "0":
+                kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
+            else:   # experiment: no events at all, the launch period stands in for the kernel time
+                kernel_ms = elapsed / max(1, n_pairs) * 1e3
             u_d = torch.stack([P[cur], P[prev], P[third]])
         else:
             for t in range(W):
