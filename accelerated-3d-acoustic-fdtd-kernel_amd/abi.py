@@ -106,6 +106,8 @@ def lib():
     L.fdtd_hip_one_step_slab.restype = C.c_int
     L.fdtd_hip_fused_launch_count.argtypes = []
     L.fdtd_hip_fused_launch_count.restype = C.c_long
+    L.fdtd_hip_two_steps_fuses.argtypes = [C.POINTER(Geom), C.c_int, C.c_int]
+    L.fdtd_hip_two_steps_fuses.restype = C.c_int
     L.fdtd_hip_small_step_count.argtypes = []
     L.fdtd_hip_small_step_count.restype = C.c_long
     L.fdtd_hip_one_step.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]

@@ -122,11 +122,14 @@ __device__ __forceinline__ f32x2 update_pair(const Coef2 &k, f32x2 uc, f32x2 xm2
   const f32x2 num = k.dt2 * (k.r2 * dxx + k.r3 * dyy + k.r4 * dzz - (k.neg2r1 * uc + k.r1 * up) * mc);
   return f32x2{num.x / mc.x, num.y / mc.y};
 }
+// edge_r: this lane's right neighbours are eR even though it is not lane 63 (the last lane of a row
+// that ends inside the wave).
 __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, f32x4 xm1, f32x4 xp1, f32x4 xp2,
                                             f32x4 ym2, f32x4 ym1, f32x4 yp1, f32x4 yp2, f32x2 eL, f32x2 eR, f32x4 up,
-                                            f32x4 mc) {
+                                            f32x4 mc, bool edge_r = false) {
   const f32x2 l = f32x2{dpp_prev(eL.x, c.z), dpp_prev(eL.y, c.w)};   // cells z-2, z-1 of cell 0
-  const f32x2 r = f32x2{dpp_next(eR.x, c.x), dpp_next(eR.y, c.y)};   // cells z+1, z+2 of cell 3
+  f32x2 r = f32x2{dpp_next(eR.x, c.x), dpp_next(eR.y, c.y)};         // cells z+1, z+2 of cell 3
+  r = edge_r ? eR : r;
   const f32x2 cl = lo2(c), ch = hi2(c);
   // cells 0,1: z-2: (l.x, l.y)  z+2: (c.z, c.w)   z-1: (l.y, c.x)  z+1: (c.y, c.z)
   // cells 2,3: z-2: (c.x, c.y)  z+2: (r.x, r.y)   z-1: (c.y, c.z)  z+1: (c.w, r.x)
@@ -142,7 +145,12 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // ZH = 2: rows of 512 cells, the two waves (q, 0) and (q, 1) hold the two z-halves of the same rows.
 // ZH = 1: rows of 256 cells; the workgroup then carries two independent 8-row tiles stacked in y,
 // h selects the tile (each computes its own redundant rows; the LDS columns 0..63 / 64..127 are theirs).
-template <bool NT, int ZH>
+// MASK: the last z-tile may end inside the tile (rows whose length is not a multiple of the tile
+// width) and the last y-tile may have fewer than 8 rows inside the box.  Lanes beyond the end of
+// the row and rows beyond y_M compute on clamped addresses and store nothing; the last lane inside
+// the row takes its right neighbours from the edge loads (as lane 63 of a full row does), and a
+// row beyond y_M contributes what the C level holds there in memory, like any other halo row.
+template <bool NT, int ZH, bool MASK>
 __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt, int wg_base) {
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
@@ -162,22 +170,33 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int yrow[3] = {yb + 2 + q, q < 2 ? yb + q : yb + 4 + q, q < 2 ? yb - 2 + q : yb + 6 + q};
   const int cslot[3] = {4 + q, q < 2 ? 2 + q : 6 + q, q < 2 ? q : 8 + q};
   const bool seg2_outside = yrow[2] < a.y_m || yrow[2] > a.y_M;
+  // MASK: an output row may lie beyond y_M as well (never below y_m: tiles start at y_m)
+  const bool out0 = MASK && yrow[0] > a.y_M, out1 = MASK && yrow[1] > a.y_M;
   const int yhalo = q < 2 ? yb - 4 + q : yb + 8 + q;   // B row outside the 12-row stack
   const int hslot = q < 2 ? q : 12 + q;
   const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
   const int lz = ZH == 2 ? lc : lane;                   // float4 index inside the row of cells
   const bool seam_lane = (lz == 0 && zt > 0) || (lz == 64 * ZH - 1 && zt < nzt - 1);   // next to a z-cut
+  // MASK: float4s of this z-tile that are inside the row; lanes from nvalid on work on the address
+  // of float4 `nvalid` (the four halo cells behind the row) and store nothing
+  const int nvalid = MASK ? min(64 * ZH, (a.z_M + 1 - zb) >> 2) : 64 * ZH;
+  const bool lane_valid = !MASK || lz < nvalid;
+  const bool last_valid = MASK && lz == nvalid - 1;        // its right neighbours come from the edge loads
+  const bool edge_hi = (lane == 63 && lane_valid) || last_valid;
+  // the row ends in this wave or before it: nothing to the right of the wave comes from LDS
+  const bool row_ends_here = MASK && nvalid <= (ZH == 2 ? (h + 1) * 64 : 64);
   // Addresses: descriptor base + scalar offset (plane + row, wave-uniform) + one lane offset along z.
   // vz: the lane's 4 cells; vze: the 2 cells before them, or behind them in the last lane; vzc: the
-  // same for the C array, where only the two cells before lane 0 / behind lane 63 are ever used, so
-  // the lanes in between repeat lane 0's address instead of touching the whole row.
-  const unsigned vz = (unsigned)(zb + lz * 4 + FDTD_HALO) * 4u;
-  const unsigned vze = lane == 63 ? vz + 16u : vz - 8u;
-  const unsigned vzc = lane == 63 ? vz + 16u : vz - (unsigned)lane * 16u - 8u;
-  int rowoff[3];   // byte offset of the segment's row inside a plane
+  // same for the C array, where only the two cells before lane 0 / behind the last lane are ever
+  // used, so the lanes in between repeat lane 0's address instead of touching the whole row.
+  const unsigned vz0 = (unsigned)(zb + (lz - lane) * 4 + FDTD_HALO) * 4u;   // lane 0 of this wave
+  const unsigned vz = (unsigned)(zb + (MASK ? min(lz, nvalid) : lz) * 4 + FDTD_HALO) * 4u;
+  const unsigned vze = edge_hi ? vz + 16u : vz - 8u;
+  const unsigned vzc = edge_hi ? vz + 16u : vz0 - 8u;
+  int rowoff[3];   // byte offset of the segment's row inside a plane (MASK: rows clamped to the array)
 #pragma unroll
-  for (int s = 0; s < 3; ++s) rowoff[s] = (yrow[s] + FDTD_HALO) * a.sy * 4;
-  const int rowoff_h = (yhalo + FDTD_HALO) * a.sy * 4;
+  for (int s = 0; s < 3; ++s) rowoff[s] = ((MASK ? min(yrow[s], a.y_M + 4) : yrow[s]) + FDTD_HALO) * a.sy * 4;
+  const int rowoff_h = ((MASK ? min(yhalo, a.y_M + 4) : yhalo) + FDTD_HALO) * a.sy * 4;
   const int sxb = (int)(a.sx * 4);   // bytes per plane
 
   // descriptors are based at the lowest plane this workgroup touches, so that plane offsets stay
@@ -252,7 +271,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, (sp + (i - 2) * sxb) + rowoff[s], vz);
-    av[s] = s == 0 ? LD4S(rA, sp + rowoff[s], vz) : LD4(rA, sp + rowoff[s], vz);
+    if (MASK && ((s == 0 && out0) || (s == 1 && out1))) av[s] = LD4(rC, sp + rowoff[s], vz);   // the C row itself
+    else av[s] = s == 0 ? LD4S(rA, sp + rowoff[s], vz) : LD4(rA, sp + rowoff[s], vz);
     mv[s] = s == 0 ? LD4S(rM, sp + rowoff[s], vz) : LD4(rM, sp + rowoff[s], vz);
     be[s] = LD2(rB, sp + rowoff[s], vze);
   }
@@ -305,17 +325,21 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
         const f32x4 ym2 = Bbuf[buf][r][lc], ym1 = Bbuf[buf][r + 1][lc];
         const f32x4 yp1 = Bbuf[buf][r + 3][lc], yp2 = Bbuf[buf][r + 4][lc];
         cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
-                          mv[s]);
+                          mv[s], last_valid);
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
+        if constexpr (MASK && s < 2) cnew = (s == 0 ? out0 : out1) ? av[s] : cnew;
         if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
       } else {   // halo plane of the domain: the intermediate level keeps what memory holds there
         cnew = LD4(rC, sp + rowoff[s], vz);
       }
+      const bool row_out = s == 0 ? out0 : (s == 1 ? out1 : false);
       if constexpr (s < 2) {
-        if (store_c) st4<NT>(rC, sp + rowoff[s], vz, cnew);
+        if (store_c && !row_out) {
+          if (lane_valid) st4<NT>(rC, sp + rowoff[s], vz, cnew);
+        }
         // planes before and behind the chunk: their C exists only here, and seam_kernel needs it
         // next to the z-cuts (a chunk beside this one, or the owner of the plane, stores the same bits)
-        else if (!STEADY && plane_inside && seam_lane) st4<false>(rC, sp + rowoff[s], vz, cnew);
+        else if (!STEADY && !store_c && !row_out && plane_inside && seam_lane) st4<false>(rC, sp + rowoff[s], vz, cnew);
       }
       Cring[ring_w][r][lc] = cnew;
       // ---- D(p-2) ----
@@ -327,12 +351,14 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
           if constexpr (ZH == 2) {   // the other z-half of the same row is in LDS
             const f32x4 nb = Cring[ring_r][r][h ? 63 : 64];
             if (h) eL = f32x2{nb.z, nb.w};
-            else eR = f32x2{nb.x, nb.y};
+            else if (!row_ends_here) eR = f32x2{nb.x, nb.y};
           }
           f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
-                               PB(0)[s], mh[0][s]);
+                               PB(0)[s], mh[0][s], last_valid);
           if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
-          st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vz, o);
+          if (!row_out) {
+            if (lane_valid) st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vz, o);
+          }
         }
         if (STEADY) {
           PC(4)[s] = cnew;
@@ -362,7 +388,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
         Bbuf[buf ^ 1][r + 2][lc] = bc[2][s];
         bc[4][s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);
       }
-      av[s] = s == 0 ? LD4S(rA, sq + rowoff[s], vz) : LD4(rA, sq + rowoff[s], vz);
+      if (MASK && ((s == 0 && out0) || (s == 1 && out1))) av[s] = LD4(rC, sq + rowoff[s], vz);
+      else av[s] = s == 0 ? LD4S(rA, sq + rowoff[s], vz) : LD4(rA, sq + rowoff[s], vz);
       mv[s] = s == 0 ? LD4S(rM, sq + rowoff[s], vz) : LD4(rM, sq + rowoff[s], vz);
       be[s] = LD2(rB, sq + rowoff[s], vze);
     };
@@ -505,33 +532,63 @@ int env_int2(const char *name, int fallback) {
 
 }  // namespace
 
+// How the (y, z) cross-section of a box is cut into tiles: rows of 512 cells in tiles of 8 rows
+// ("wide"), or rows of 256 cells with two 8-row tiles per workgroup.  Whichever wastes less of
+// its lanes and rows on padding is taken; a cross-section that does not fill its tiles exactly
+// runs the kernel's MASK variant.
+struct M2Tiling {
+  bool wide, mask;
+  int zstep, tile_rows, nyt, nzt;
+  double fill;   // cells of the cross-section / cells the tiles span
+};
+static M2Tiling m2_tiling(int ey, int ez) {
+  auto make = [&](bool wide) {
+    M2Tiling t;
+    t.wide = wide;
+    t.zstep = wide ? M2_ZCELLS : M2_ZCELLS / 2;
+    t.tile_rows = wide ? M2_ROWS : 2 * M2_ROWS;
+    t.nyt = (ey + t.tile_rows - 1) / t.tile_rows;
+    t.nzt = (ez + t.zstep - 1) / t.zstep;
+    t.mask = (ez % t.zstep) != 0 || (ey % t.tile_rows) != 0;
+    t.fill = (double)ey * ez / ((double)t.nyt * t.tile_rows * t.nzt * t.zstep);
+    return t;
+  };
+  const M2Tiling w = make(true), n = make(false);
+  return w.fill >= n.fill ? w : n;
+}
+
 // Can the fused kernel take this problem?  (Everything else goes through two single sweeps.)
 bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float *b, const float *a_prev,
                           const float *c, const float *d, int nsrc) {
   if (!g) return false;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
-  // rows of k * 512 cells in tiles of 8 rows, or rows of k * 256 cells in pairs of such tiles
-  const int tile_rows = ez % M2_ZCELLS ? 2 * M2_ROWS : M2_ROWS;
-  if (ex < 1 || ez % (M2_ZCELLS / 2) || ez < 1 || ey < tile_rows || ey % tile_rows) return false;
+  // rows of whole float4s, at least one tile's worth of rows
+  if (ex < 1 || ez < 4 || ez % 4 || ey < M2_ROWS) return false;
+  // a row that ends with the first float4 of a wave would make that lane both the first and the last
+  // of its wave, and a lane holds the edge cells of one side only
+  if (((ez >> 2) & 63) == 1) return false;
   if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
   if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
   if (((long)g->nyp * g->nzp) % 4) return false;
-  // the kernel touches planes x_m-4 .. x_M+4 and rows y_m-4 .. y_M+4 of the padded arrays
+  // the kernel touches planes x_m-4 .. x_M+4 and rows y_m-4 .. y_M+4 of the padded arrays, and in a
+  // row the cells up to z_M+4 (lanes beyond the end of a row work on its four halo cells)
   if (g->x_m < 0 || g->x_M + FDTD_HALO + 4 > g->nxp - 1) return false;
   if (g->y_m < 0 || g->y_M + FDTD_HALO + 4 > g->nyp - 1) return false;
-  if (g->z_M + FDTD_HALO + 2 > g->nzp - 1) return false;
+  if (g->z_M + FDTD_HALO + 4 > g->nzp - 1) return false;
   if (nsrc > M2_MAX_SRC) return false;
   return true;
 }
 
-// Does the automatic choice take the fused kernel for an eligible problem?  Rows of k * 512 cells,
-// or of k * 256 cells from 768 on, over at least FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges
-// spend too much on the four planes of u(time+1) each chunk recomputes, and a grid with rows of 256
-// cells sits in the last-level cache, where the marching kernel was the faster one (256^3: 300
-// against 253 Gcells/s), so that one is fused only on explicit request.
+// Does the automatic choice take the fused kernel for an eligible problem?  At least
+// FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of u(time+1)
+// each chunk recomputes.  Tiles filled to at least FDTD_FUSE2_MIN_FILL percent (80): the fused sweep
+// is about 1.25 times as fast as the marching kernel per cell it spans.  And not a single row of 256
+// cells: such a grid sits in the last-level cache, where the marching kernel was the faster one
+// (256^3: 300 against 253 Gcells/s); that one is fused only on explicit request.
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
-  const int ex = g->x_M - g->x_m + 1, ez = g->z_M - g->z_m + 1;
-  return (ez % M2_ZCELLS == 0 || (ez % (M2_ZCELLS / 2) == 0 && ez > M2_ZCELLS)) &&
+  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
+  const M2Tiling t = m2_tiling(ey, ez);
+  return (t.wide || ez > M2_ZCELLS) && 100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 80) &&
          ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 
@@ -584,11 +641,9 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // is what makes one of two requests for a shared row hit in L2 (all rounds in one launch:
   // 1024^3 at 372 instead of 437 Gcells/s).
   const int ez = g->z_M - g->z_m + 1;
-  const bool wide = ez % M2_ZCELLS == 0;                     // z-tiles of 512 cells, else of 256
-  const int zstep = wide ? M2_ZCELLS : M2_ZCELLS / 2;
-  const int tile_rows = wide ? M2_ROWS : 2 * M2_ROWS;
-  const int nyt = ey / tile_rows > 0 ? ey / tile_rows : 1;
-  const int nzt = ez / zstep > 0 ? ez / zstep : 1;
+  const M2Tiling tl = m2_tiling(ey, ez);
+  const bool wide = tl.wide;                                 // z-tiles of 512 cells, else of 256
+  const int zstep = tl.zstep, nyt = tl.nyt, nzt = tl.nzt;
   const int ntile = nyt * nzt;
   // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
   const long plane_bytes = (long)g->nyp * g->nzp * 4;
@@ -730,22 +785,22 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     for (long base = 0; base < total; base += per_launch) {
       const dim3 grid((unsigned)(total - base < per_launch ? total - base : per_launch)), block(512);
       const int b = (int)base;
-      if (dispatch_times) {
-        if (wide && nt)
-          hipExtLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, ev_begin, ev_end, 0, a, xchunk, nyt, nzt, b);
-        else if (wide)
-          hipExtLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, ev_begin, ev_end, 0, a, xchunk, nyt, nzt, b);
-        else if (nt)
-          hipExtLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, ev_begin, ev_end, 0, a, xchunk, nyt, nzt, b);
-        else
-          hipExtLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, ev_begin, ev_end, 0, a, xchunk, nyt, nzt, b);
-      } else if (wide) {
-        if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 2>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
-        else hipLaunchKernelGGL((stencil_march2_kernel<false, 2>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
+#define M2_LAUNCH(NT_, ZH_, MASK_)                                                                          \
+  do {                                                                                                       \
+    if (dispatch_times)                                                                                      \
+      hipExtLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_>), grid, block, 0, s, ev_begin, ev_end, 0, a, \
+                            xchunk, nyt, nzt, b);                                                            \
+    else                                                                                                     \
+      hipLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_>), grid, block, 0, s, a, xchunk, nyt, nzt, b); \
+  } while (0)
+      if (wide) {
+        if (tl.mask) { if (nt) M2_LAUNCH(true, 2, true); else M2_LAUNCH(false, 2, true); }
+        else { if (nt) M2_LAUNCH(true, 2, false); else M2_LAUNCH(false, 2, false); }
       } else {
-        if (nt) hipLaunchKernelGGL((stencil_march2_kernel<true, 1>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
-        else hipLaunchKernelGGL((stencil_march2_kernel<false, 1>), grid, block, 0, s, a, xchunk, nyt, nzt, b);
+        if (tl.mask) { if (nt) M2_LAUNCH(true, 1, true); else M2_LAUNCH(false, 1, true); }
+        else { if (nt) M2_LAUNCH(true, 1, false); else M2_LAUNCH(false, 1, false); }
       }
+#undef M2_LAUNCH
       __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
     }
   }
@@ -817,6 +872,15 @@ extern "C" int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m,
   const int own_hi = (g->x_M + x_shift == global_nx - 1 ? global_nx : g->x_M + x_shift);
   return fdtd_inject_level(g, m, src, src_coords, next, time, p_src_m, p_src_M, src_stride, coord_stride, x_shift,
                            own_lo, own_hi, 0, 0, 0, stream);
+}
+
+// Would fdtd_hip_two_steps run this box (with nsrc sources and 16-byte aligned levels) as the fused
+// sweep?  variant as there; lets a caller choose its schedule or its accounting beforehand.
+extern "C" int fdtd_hip_two_steps_fuses(const struct fdtd_geom *g, int nsrc, int variant) {
+  if (!g || (variant != FDTD_VARIANT_AUTO && variant != FDTD_VARIANT_MARCH2)) return 0;
+  if (env_int2("FDTD_FUSE2", 1) == 0) return 0;
+  if (!fdtd_march2_eligible(g, nullptr, nullptr, nullptr, nullptr, nullptr, nsrc)) return 0;
+  return (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g)) ? 1 : 0;
 }
 
 // Number of two-step sweep launches issued by this process so far (lets a caller or a test see

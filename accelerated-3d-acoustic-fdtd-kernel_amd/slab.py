@@ -467,10 +467,13 @@ class HipStepper:
         import os
         if os.environ.get("FDTD_SLAB_OVERLAP", "1") == "0":
             return False
-        nyp, nzp = prop.levels[0].shape[1:]
-        nz, ny = nzp - 2 * HALO, nyp - 2 * HALO
-        return (((nz % 512 == 0 and ny % 8 == 0) or (nz == 256 and ny % 16 == 0)) and prop.nsrc <= 8
-                and os.environ.get("FDTD_FUSE2", "1") != "0" and self.variant in (-1, abi.VARIANTS["march2"]))
+        if self.variant not in (-1, abi.VARIANTS["march2"]):
+            return False
+        # the interior range of the split slab, as the library will see it
+        nxp, nyp, nzp = prop.levels[0].shape
+        g = abi.Geom(nxp, nyp, nzp, PAIR_GHOST, prop.nx - PAIR_GHOST - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1,
+                     prop.dt, prop.h[0], prop.h[1], prop.h[2], prop.o[0], prop.o[1], prop.o[2])
+        return bool(self.lib.fdtd_hip_two_steps_fuses(C.byref(g), prop.nsrc, abi.VARIANTS["march2"]))
 
     def bind_pairs(self, prop):
         self.p = prop
@@ -499,7 +502,7 @@ class HipStepper:
         # sweep leaves free.  From 256 tiles of the fused sweep on (1024 x 1024 cells) those small
         # sweeps are starved for so long that the fused sweep itself, which stores nothing outside
         # its range either, is the cheaper way (FDTD_SLAB_ZONE_FUSED=0/1 overrides).
-        tiles = ((nyp - 2 * HALO) // 8) * ((nzp - 2 * HALO) // 512)
+        tiles = ((nyp - 2 * HALO + 7) // 8) * ((nzp - 2 * HALO + 511) // 512)
         zf = os.environ.get("FDTD_SLAB_ZONE_FUSED")
         self.zone_fused = prop.overlap and (tiles >= 256 if zf is None else zf != "0")
         self.scratch = None

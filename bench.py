@@ -118,8 +118,8 @@ def main():
             dist.init_process_group(backend)
         slab = pkg.slab
         # two steps per exchange (fused sweep, 4-plane ghosts) where the slab's cross-section allows it
-        pairs = (args.variant in ("auto", "march2") and os.environ.get("FDTD_FUSE2", "1") != "0"
-                 and n % 512 == 0 and args.storage == "f32")
+        gq = pkg.Geom(n + 8, n + 8, n + 8, 0, n - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+        pairs = args.storage == "f32" and bool(L.fdtd_hip_two_steps_fuses(C.byref(gq), 1, variant))
         maker = slab.standard_pair_benchmark if pairs else slab.SlabPropagator.standard_benchmark
         prop = maker(n_per_rank=n, ny=n, nz=n, nt=total_steps + 1, rank=rank, world=world, device=dev,
                      variant=variant, global_x=args.global_x, self_exchange=args.self_exchange and world == 1)
@@ -183,10 +183,8 @@ def main():
             fn = L.fdtd_hip_source_inject_h16 if h16 else L.fdtd_hip_source_inject
             return fn(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
 
-        # the library fuses rows of k * 512 cells (k * 256 from 768 on) by itself, rows of 256 cells only when asked to
-        fused = ((not h16) and os.environ.get("FDTD_FUSE2", "1") != "0" and
-                 ((args.variant in ("auto", "march2") and (n % 512 == 0 or (n % 256 == 0 and n > 512))) or
-                  (args.variant == "march2" and n == 256)))
+        # two steps per sweep where the library takes the fused sweep for this box
+        fused = (not h16) and bool(L.fdtd_hip_two_steps_fuses(C.byref(g), 1, variant))
         updates_per_launch = 1
         if fused:
             # Two steps per sweep: four level buffers rotate (the three ring slots and one more).  All
@@ -196,10 +194,21 @@ def main():
             P = [u_d[0], u_d[1], u_d[2], extra]
             cur, prev, third, spare = 0, 2, 1, 3          # time 0: t0 = 0, t1 = 2, t2 = 1
             margs = (m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr())
-            for t in range(W):
+            # The untimed steps take the same kernels as the timed ones (as the operators' time loop does):
+            # one single step if their number is odd, pairs for the rest.  With single steps only, the
+            # process's first launch of the two-step sweep would fall into the timed window (about 1 ms).
+            t = 0
+            if W % 2:
                 assert L.fdtd_hip_one_step(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
                                            P[third].data_ptr(), t, 0, 0, 1, 3, variant, sh) == 0
                 cur, prev, third = third, cur, prev
+                t += 1
+            while t < W:
+                assert L.fdtd_hip_two_steps_ex(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
+                                               P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, variant, 1,
+                                               None, None, sh) == 0
+                cur, prev, third, spare = spare, third, cur, prev
+                t += 2
             n_pairs = K // 2
             # Every two-step call hands the library two events.  Where the call is a single sweep launch
             # (512-wide rows) they receive the start and stop times of that dispatch itself, which is the

@@ -161,8 +161,9 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * nxp*nyp*nzp floats each: cur = u(time) and prev = u(time-1) are read, next1 =
  * u(time+1) and next2 = u(time+2) are written (interior cells only; the halo cells of
  * next1 and next2 keep their values and are read as such).  Both source scatters are
- * included.  When the shape allows (z extent a multiple of 512 and y extent a multiple of 8, or z
- * extent a multiple of 256 and y extent a multiple of 16; at most 8 sources) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
+ * included.  When the shape allows (z extent a multiple of 4, at least 8 rows, at most 8 sources; under
+ * FDTD_VARIANT_AUTO also: at least 32 planes and a cross-section that fills the sweep's tiles of
+ * 8 rows x 512 cells, or 16 x 256, to 80 %) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
  * per cell update; otherwise they run one after the other.  Either way the result is
  * bit for bit that of two single steps.  This is the time fusion the reference driver
  * has a knob for (t_fuse, main.cpp:261,267) and no reference kernel implements.
@@ -170,12 +171,16 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * hipErrorInvalidValue): unlike the reference's ring, u(time+2) cannot be written over
  * u(time-1), because neighbouring workgroups still read it.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
  * the fusion, any other variant selects the single-step kernel used for both sweeps.
- * FDTD_VARIANT_MARCH2 fuses regardless of the x range and also at a z extent of exactly
- * 256 (AUTO leaves that one to the single-step kernel, which is faster there). */
+ * FDTD_VARIANT_MARCH2 fuses whatever the x range and the fill, and also at a z extent of
+ * 256 or less (AUTO leaves those to the single-step kernel, which is faster there). */
 int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
                        const float *src_coords, const float *cur, const float *prev,
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,
                        int src_stride, int coord_stride, int variant, void *stream);
+
+/* Would fdtd_hip_two_steps take the fused sweep for this box with nsrc sources (levels assumed
+ * 16-byte aligned)?  1 or 0; variant as for fdtd_hip_two_steps. */
+int fdtd_hip_two_steps_fuses(const struct fdtd_geom *g, int nsrc, int variant);
 
 /* Statistics: how many two-step sweep kernels this process has launched so far (tells a
  * caller whether its calls were fused or ran as two sweeps). */

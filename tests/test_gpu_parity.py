@@ -226,14 +226,19 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((48, 64, 256), 2, "march2"), ((300, 256, 256), 1, "march2"),
                                                 ((24, 8, 512), 0, "march2"), ((520, 512, 512), 1, "auto"),
                                                 ((20, 16, 1024), 3, "march2"), ((70, 24, 1536), 2, "auto"),
-                                                ((40, 32, 768), 2, "auto"), ((300, 1024, 1024), 2, "auto")])
+                                                ((40, 32, 768), 2, "auto"), ((300, 1024, 1024), 2, "auto"),
+                                                ((20, 20, 640), 2, "march2"), ((24, 13, 520), 2, "march2"),
+                                                ((40, 100, 264), 3, "march2"), ((36, 9, 252), 2, "march2"),
+                                                ((40, 44, 480), 2, "auto"), ((34, 500, 1000), 2, "auto")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
     one launch, forced fusion on a short x range, rows of 256 cells (fused on request only), no
     sources, an x range long enough to be cut into two launches (520 planes at 64 y-tiles), and rows
     of 1024, 1536 and 768 cells (two and three z-tiles of 512, three of 256; the cells around the cuts
-    are redone by the seam pass); the last shape is a full cross-section of 256 tiles in three launches."""
+    are redone by the seam pass); a full cross-section of 256 tiles in three launches; and cross-sections
+    that do not fill their tiles (rows ending inside a z-tile, inside the first half of one, eight cells into
+    one; fewer than 8 or 16 rows in the last y-tile), which run the masked variant of the kernel."""
     import torch
     nx, ny, nz = shape
     gen = torch.Generator(device="cuda").manual_seed(1234)
@@ -338,6 +343,28 @@ def test_two_steps_rejects_overlapping_levels(pkg, hiplib):
     assert call(P[0], P[1], P[2], P[2] + 4096) == 1   # partial overlap
     assert call(P[0], P[1], m.data_ptr(), P[3]) == 1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name", list(cases.CASES))
+def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, monkeypatch):
+    """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s, at least 8 rows and at
+    most 8 sources goes through the two-step sweep (masked tiles for all but the fused_z* shapes), the others
+    through the ordinary loop; the bytes are the fixture's either way."""
+    monkeypatch.setenv("FDTD_VARIANT", "march2")
+    c = cases.build(name, pkg)
+    before = hiplib.fdtd_hip_fused_launch_count()
+    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
+    assert rc == 0
+    check_against_golden(name, c["u"], exact=True)
+    n = c["u"].shape[1:]
+    b = c["kw"].get("bounds") or (0, n[0] - 9, 0, n[1] - 9, 0, n[2] - 9)
+    ex, ey, ez = b[1] - b[0] + 1, b[3] - b[2] + 1, b[5] - b[4] + 1
+    time_M = c["kw"].get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
+    n_steps = time_M - c["kw"].get("time_m", 0) + 1
+    lo, hi = c["kw"].get("p_src", (0, (c["coords"].shape[0] if c["coords"] is not None else 0) - 1))
+    fusable = (ex >= 1 and ey >= 8 and ez % 4 == 0 and (ez // 4) % 64 != 1 and b[4] % 4 == 0 and hi - lo + 1 <= 8 and n_steps >= 4
+               and b[5] + 8 <= n[2] - 1 and b[3] + 8 <= n[1] - 1 and b[1] + 8 <= n[0] - 1)
+    assert (hiplib.fdtd_hip_fused_launch_count() > before) == fusable, name
 
 
 def test_t_fuse_knob_requests_fused_sweep(pkg, hiplib):
