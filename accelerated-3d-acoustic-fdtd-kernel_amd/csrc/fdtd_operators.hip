@@ -551,7 +551,10 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
 
   // FDTD_OPERATOR_TRACE=1: host-side phase times of this call on stderr
   const bool trace = getenv("FDTD_OPERATOR_TRACE") && atoi(getenv("FDTD_OPERATOR_TRACE")) != 0;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto now = [] {
+    using ms = std::chrono::duration<double, std::milli>;
+    return ms(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
   const double t_begin = now();
   double t_alloc = 0, t_h2d = 0, t_loop = 0, t_d2h = 0;
   DeviceBuffers d;

@@ -302,7 +302,8 @@ def main():
                          f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, "
                          + ("two steps per sweep and exchange (4 ghost planes of u(t+2) per side)" if updates_per_launch == 2
                             else "2-plane ghost exchange per step")
-                         + f" over {'RCCL' if os.environ.get('FDTD_BENCH_BACKEND', 'nccl') == 'nccl' else 'gloo (host-staged rehearsal)'}"
+                         + (" over RCCL" if os.environ.get("FDTD_BENCH_BACKEND", "nccl") == "nccl"
+                            else " over gloo (host-staged rehearsal)")
                          + f", {total_steps} steps ({W} untimed)"),
             "variant": args.variant,
             "bytes_per_cell_update": ALGO_BYTES_PER_CELL,
