@@ -8,7 +8,7 @@ timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -
 python3 - "$O" <<'PY'
 import csv, glob, json, sys
 O = sys.argv[1]
-out = {"workload": "bench.py --grid 1024 --steps 10 (5 two-step calls)"}
+out = {"workload": "bench.py --grid 1024 --steps 10 (all two-step calls of the run, untimed ones included)"}
 for d, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     rows = list(csv.DictReader(open(glob.glob(f"{O}/{d}/*/*_counter_collection.csv")[0])))
     for k in ("stencil_march2", "seam_kernel"):
