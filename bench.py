@@ -112,6 +112,12 @@ def main():
         # "nccl" is RCCL on ROCm.  FDTD_BENCH_BACKEND=gloo stages the ghosts through the host
         # (for rehearsing this path with several ranks on one GPU; never a performance number).
         backend = os.environ.get("FDTD_BENCH_BACKEND", "nccl")
+        # RCCL prints a version banner on stdout when its first communicator comes up; this program's
+        # stdout carries one JSON line and nothing else, so file descriptor 1 points at stderr until the
+        # untimed steps are through.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if backend == "nccl":
             pkg.slab.init_rccl(dev)
         else:
@@ -140,6 +146,9 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
         t_start = time.perf_counter()
         advance(W, total_steps)
         t_issue = time.perf_counter() - t_start
