@@ -45,6 +45,42 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
         pkg.abi.lib()
 
 
+@pytest.mark.parametrize("n,nsrc,variant,expect", [
+    ((512, 512, 512), 1, "auto", 1),      # full tiles of 8 rows x 512 cells
+    ((1024, 1024, 1024), 1, "auto", 1),   # two z-tiles
+    ((768, 768, 768), 1, "auto", 1),      # three z-tiles of 256
+    ((500, 500, 500), 1, "auto", 1),      # masked tiles, 97 % full
+    ((640, 640, 640), 1, "auto", 1),      # 83 %
+    ((384, 384, 384), 1, "auto", 0),      # 75 %: left to the marching kernel ...
+    ((384, 384, 384), 1, "march2", 1),    # ... unless asked for
+    ((256, 256, 256), 1, "auto", 0),      # a single row of 256 cells
+    ((256, 256, 256), 1, "march2", 1),
+    ((20, 512, 512), 1, "auto", 0),       # fewer than 32 planes
+    ((20, 512, 512), 1, "march2", 1),
+    ((64, 64, 516), 1, "march2", 0),      # a row ending on the first float4 of a wave
+    ((64, 64, 514), 1, "march2", 0),      # rows that are not whole float4s
+    ((64, 7, 512), 1, "march2", 0),       # fewer than 8 rows
+    ((512, 512, 512), 9, "march2", 0),    # more than 8 sources
+    ((512, 512, 512), 8, "auto", 1),
+    ((512, 512, 512), 1, "march", 0),     # a single-step variant by name
+])
+def test_which_boxes_take_the_fused_sweep(pkg, hiplib, n, nsrc, variant, expect):
+    """fdtd_hip_two_steps_fuses: the host-side rule for which boxes fdtd_hip_two_steps runs as one fused
+    sweep (pure host logic, no device call)."""
+    g = pkg.Geom(n[0] + 8, n[1] + 8, n[2] + 8, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+    assert hiplib.fdtd_hip_two_steps_fuses(C.byref(g), nsrc, pkg.VARIANTS[variant]) == expect
+
+
+def test_fused_sweep_switch_and_unpadded_arrays(pkg, hiplib, monkeypatch):
+    n = (512, 512, 512)
+    g = pkg.Geom(n[0] + 8, n[1] + 8, n[2] + 8, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+    # arrays with less than 4 cells of padding behind the box: the sweep would read beyond them
+    tight = pkg.Geom(n[0] + 8, n[1] + 8, n[2] + 6, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+    assert hiplib.fdtd_hip_two_steps_fuses(C.byref(tight), 1, pkg.VARIANTS["auto"]) == 0
+    monkeypatch.setenv("FDTD_FUSE2", "0")
+    assert hiplib.fdtd_hip_two_steps_fuses(C.byref(g), 1, pkg.VARIANTS["auto"]) == 0
+
+
 def test_ricker_generator(pkg):
     src = pkg.fill_ricker(50, 3)
     assert src.shape == (50, 3) and (src[:, 0] == src[:, 2]).all()
