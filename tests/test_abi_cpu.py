@@ -75,7 +75,7 @@ def test_fused_sweep_switch_and_unpadded_arrays(pkg, hiplib, monkeypatch):
     n = (512, 512, 512)
     g = pkg.Geom(n[0] + 8, n[1] + 8, n[2] + 8, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
     # arrays with less than 4 cells of padding behind the box: the sweep would read beyond them
-    tight = pkg.Geom(n[0] + 8, n[1] + 8, n[2] + 6, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+    tight = pkg.Geom(n[0] + 8, n[1] + 8, n[2] + 4, 0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
     assert hiplib.fdtd_hip_two_steps_fuses(C.byref(tight), 1, pkg.VARIANTS["auto"]) == 0
     monkeypatch.setenv("FDTD_FUSE2", "0")
     assert hiplib.fdtd_hip_two_steps_fuses(C.byref(g), 1, pkg.VARIANTS["auto"]) == 0
