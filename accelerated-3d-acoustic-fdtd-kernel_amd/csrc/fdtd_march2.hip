@@ -25,10 +25,12 @@
 // counted waits).  Memory is addressed with buffer instructions: descriptor (scalar) + plane
 // offset (scalar) + one loop-invariant 32-bit lane offset per row.
 //
-// Shapes: z extent a multiple of 512 cells with a y extent that is a multiple of 8, or z extent a
-// multiple of 256 with a y extent that is a multiple of 16 (the workgroup then carries two 8-row
-// tiles of 256-cell rows, one per wave parity); at most 8 sources; anything else is run as two
-// single sweeps by fdtd_hip_two_steps.
+// Shapes: tiles of 8 rows x 512 cells, or of 16 rows x 256 cells (the workgroup then carries two
+// 8-row tiles of 256-cell rows, one per wave parity), whichever the cross-section fills better; a
+// cross-section that does not fill its tiles runs the MASK instantiation.  Rows must be whole
+// float4s and there must be at least 8 of them; anything else is run as two single sweeps by
+// fdtd_hip_two_steps.  Up to 8 sources are scattered by the sweep itself, more by passes behind
+// it (repair_kernel).
 // Longer rows are cut into z-tiles of 512 (or 256) cells.  A tile cannot know its neighbour's C
 // beyond the cut in time, so the four D cells around every cut (two on either side) come out wrong
 // and are recomputed by seam_kernel after the sweep, from the C level in memory; the second scatter
@@ -476,6 +478,46 @@ __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
   *(Quad *)(a.D + i) = o;
 }
 
+// More than 8 sources do not fit the sweep's one-lane-per-corner scatter.  The sweep then runs
+// without sources, the first scatter is applied to the C level in memory afterwards, and this
+// kernel recomputes D on the cells whose stencil contains a scattered cell: the 13 cells of the
+// star around every corner that landed inside the box (same expression as the sweep and the seam
+// pass; recomputing a cell twice gives the same bits).  The second scatter follows as a launch of
+// its own.  One thread per (corner, star cell).
+struct RepairArgs {
+  const float *C, *B, *m, *coords;
+  float *D;
+  long sx;
+  int sy, x_m, x_M, y_m, y_M, z_m, z_M;
+  int p_src_m, nsrc, coord_stride;
+  float h_x, h_y, h_z, o_x, o_y, o_z;
+  Coef2 k;
+};
+__global__ __launch_bounds__(256) void repair_kernel(RepairArgs a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= a.nsrc * 8 * 13) return;
+  const int star = tid % 13, corner = (tid / 13) & 7, p = a.p_src_m + tid / (13 * 8);
+  const int rx = (corner >> 2) & 1, ry = (corner >> 1) & 1, rz = corner & 1;
+  // positions as openacc.cpp:185-187 computes them
+  const float gx = (-a.o_x + a.coords[(long)p * a.coord_stride + 0]) / a.h_x;
+  const float gy = (-a.o_y + a.coords[(long)p * a.coord_stride + 1]) / a.h_y;
+  const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
+  const int tx = rx + (int)floorf(gx), ty = ry + (int)floorf(gy), tz = rz + (int)floorf(gz);
+  // corners outside the box were in memory before the sweep started: it has seen them
+  if (tx < a.x_m || tx > a.x_M || ty < a.y_m || ty > a.y_M || tz < a.z_m || tz > a.z_M) return;
+  // star cell: 0 = the corner's cell, 1..4 = x-2, x-1, x+1, x+2, then y, then z
+  const int axis = star == 0 ? -1 : (star - 1) / 4, d = star == 0 ? 0 : ((star - 1) % 4 < 2 ? (star - 1) % 4 - 2 : (star - 1) % 4 - 1);
+  const int x = tx + (axis == 0 ? d : 0), y = ty + (axis == 1 ? d : 0), z = tz + (axis == 2 ? d : 0);
+  if (x < a.x_m || x > a.x_M || y < a.y_m || y > a.y_M || z < a.z_m || z > a.z_M) return;
+  const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
+  auto two = [](float v) { return f32x2{v, v}; };
+  const float *C = a.C;
+  const f32x2 o = update_pair(a.k, two(C[i]), two(C[i - 2 * a.sx]), two(C[i - a.sx]), two(C[i + a.sx]), two(C[i + 2 * a.sx]),
+                              two(C[i - 2 * a.sy]), two(C[i - a.sy]), two(C[i + a.sy]), two(C[i + 2 * a.sy]),
+                              two(C[i - 2] + C[i + 2]), two(C[i - 1] + C[i + 1]), two(a.B[i]), two(a.m[i]));
+  a.D[i] = o.x;
+}
+
 // The shell: the two layers of cells around the updated box, i.e. every halo cell a sweep can
 // read (openacc.cpp:161-163) or a scatter can touch (openacc.cpp:192).  One wave per (x, y) row
 // of the box grown by 2; rows outside the box in x or y are copied whole, rows inside it only
@@ -575,7 +617,7 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
   if (g->x_m < 0 || g->x_M + FDTD_HALO + 4 > g->nxp - 1) return false;
   if (g->y_m < 0 || g->y_M + FDTD_HALO + 4 > g->nyp - 1) return false;
   if (g->z_M + FDTD_HALO + 4 > g->nzp - 1) return false;
-  if (nsrc > M2_MAX_SRC) return false;
+  (void)nsrc;   // more than 8 sources: the sweep runs without them and the cells around them are redone
   return true;
 }
 
@@ -676,8 +718,11 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     }
   }
   const bool offsets_ok = xchunk <= addressable;
+  // More than 8 sources: scatter and repair passes after the sweep work on the C level in memory,
+  // which holds the planes beside the range only when the range is the whole domain.
+  const bool many = nsrc > M2_MAX_SRC;
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
-                    env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok &&
+                    env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok && !(many && global_nx > 0) &&
                     fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
                     (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g));
 
@@ -695,7 +740,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // dispatch itself (what a profiler reports as the kernel's duration); otherwise they are
   // recorded on the stream around everything the call launches.
   const int per_launch = env_int2("FDTD_FUSE2_WGS", ntile > 256 ? ntile : 256);
-  const bool dispatch_times = fuse && ev_begin && ev_end && nzt == 1 &&
+  const bool dispatch_times = fuse && ev_begin && ev_end && nzt == 1 && !many &&
                               (long)ntile * ((ex + xchunk - 1) / xchunk) <= per_launch;
   if (ev_begin && !dispatch_times) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
 
@@ -760,7 +805,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.dx_m = dx_m; a.dx_M = dx_M;
   a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
-  a.scatter_d = nzt == 1;
+  a.scatter_d = nzt == 1 && !many;
   a.keep_lo = (flags & 4) != 0;
   a.keep_hi = (flags & 8) != 0;
   a.k.cm2 = -8.33333333e-2F; a.k.cm1 = 1.333333330F; a.k.c0 = -2.50F;
@@ -773,7 +818,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.src_row = has_src ? src + (long)time * src_stride : nullptr;
   a.src_row2 = has_src ? src + (long)(time + 1) * src_stride : nullptr;
   a.coords = src_coords; a.m_f = m;
-  a.nsrc = nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride; a.x_shift = x_shift;
+  a.nsrc = many ? 0 : nsrc; a.p_src_m = p_src_m; a.coord_stride = coord_stride; a.x_shift = x_shift;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
   const bool nt = env_int2("FDTD_NT", 1) != 0;
   {
@@ -804,6 +849,11 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
     }
   }
+  if (many) {   // the first scatter, on the C level in memory (corners inside the box; the others are there already)
+    const int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
+                                     x_shift, g->x_m + x_shift, g->x_M + x_shift, 2, gx_m, gx_M, stream);
+    if (rc) return rc;
+  }
   if (nzt > 1) {
     SeamArgs sa;
     sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2;
@@ -818,9 +868,20 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
                          dim3(256), 0, s, sa);
     }
   }
+  if (many) {
+    RepairArgs ra;
+    ra.C = next1; ra.B = cur; ra.m = m; ra.coords = src_coords; ra.D = next2;
+    ra.sx = a.sx; ra.sy = a.sy;
+    ra.x_m = g->x_m; ra.x_M = g->x_M; ra.y_m = g->y_m; ra.y_M = g->y_M; ra.z_m = g->z_m; ra.z_M = g->z_M;
+    ra.p_src_m = p_src_m; ra.nsrc = nsrc; ra.coord_stride = coord_stride;
+    ra.h_x = g->h_x; ra.h_y = g->h_y; ra.h_z = g->h_z; ra.o_x = g->o_x; ra.o_y = g->o_y; ra.o_z = g->o_z;
+    ra.k = a.k;
+    const long threads = (long)nsrc * 8 * 13;
+    hipLaunchKernelGGL(repair_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, ra);
+  }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  if (nzt > 1 && has_src)
+  if ((nzt > 1 || many) && has_src)
     rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
                            x_shift, g->x_m + x_shift, g->x_M + x_shift, 2, gx_m, gx_M, stream);
   if (ev_end && !dispatch_times) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));

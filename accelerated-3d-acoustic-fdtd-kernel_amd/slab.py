@@ -467,8 +467,8 @@ class HipStepper:
         import os
         if os.environ.get("FDTD_SLAB_OVERLAP", "1") == "0":
             return False
-        if self.variant not in (-1, abi.VARIANTS["march2"]):
-            return False
+        if self.variant not in (-1, abi.VARIANTS["march2"]) or prop.nsrc > 8:
+            return False      # (with more than 8 sources the slab form of the call runs as two sweeps)
         # the interior range of the split slab, as the library will see it
         nxp, nyp, nzp = prop.levels[0].shape
         g = abi.Geom(nxp, nyp, nzp, PAIR_GHOST, prop.nx - PAIR_GHOST - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1,

@@ -229,7 +229,8 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((40, 32, 768), 2, "auto"), ((300, 1024, 1024), 2, "auto"),
                                                 ((20, 20, 640), 2, "march2"), ((24, 13, 520), 2, "march2"),
                                                 ((40, 100, 264), 3, "march2"), ((36, 9, 252), 2, "march2"),
-                                                ((40, 44, 480), 2, "auto"), ((34, 500, 1000), 2, "auto")])
+                                                ((40, 44, 480), 2, "auto"), ((34, 500, 1000), 2, "auto"),
+                                                ((40, 24, 512), 20, "auto"), ((36, 20, 1024), 11, "auto")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
@@ -256,6 +257,10 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
         coords[0] = torch.tensor([(nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2]])   # corners in the halo layer
         if nz > 512 and nsrc > 1:
             coords[1, 2] = 511.5 * h[2]     # corners on either side of the cut between two z-tiles
+        if nsrc > 8:                        # more sources than the sweep scatters itself
+            coords[3] = coords[2] + torch.tensor([1.2 * h[0], 0.0, 0.6 * h[2]], device="cuda")   # overlapping stars
+            coords[5] = coords[4]                                                                  # coincident corners
+            coords[6] = torch.tensor([0.4 * h[0], 0.3 * h[1], 1.7 * h[2]], device="cuda")          # in the box's corner
 
     def run(var):
         cur, prev, n1, n2 = (t.clone() for t in lv)
@@ -347,9 +352,10 @@ def test_two_steps_rejects_overlapping_levels(pkg, hiplib):
 
 @pytest.mark.parametrize("name", list(cases.CASES))
 def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, monkeypatch):
-    """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s, at least 8 rows and at
-    most 8 sources goes through the two-step sweep (masked tiles for all but the fused_z* shapes), the others
-    through the ordinary loop; the bytes are the fixture's either way."""
+    """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s and at least 8 rows goes
+    through the two-step sweep (masked tiles for all but the fused_z* shapes; with 27 and 30 sources the
+    scatter and repair passes behind the sweep), the others through the ordinary loop; the bytes are the
+    fixture's either way."""
     monkeypatch.setenv("FDTD_VARIANT", "march2")
     c = cases.build(name, pkg)
     before = hiplib.fdtd_hip_fused_launch_count()
@@ -362,7 +368,7 @@ def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, monkeypatch):
     time_M = c["kw"].get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
     n_steps = time_M - c["kw"].get("time_m", 0) + 1
     lo, hi = c["kw"].get("p_src", (0, (c["coords"].shape[0] if c["coords"] is not None else 0) - 1))
-    fusable = (ex >= 1 and ey >= 8 and ez % 4 == 0 and (ez // 4) % 64 != 1 and b[4] % 4 == 0 and hi - lo + 1 <= 8 and n_steps >= 4
+    fusable = (ex >= 1 and ey >= 8 and ez % 4 == 0 and (ez // 4) % 64 != 1 and b[4] % 4 == 0 and n_steps >= 4
                and b[5] + 8 <= n[2] - 1 and b[3] + 8 <= n[1] - 1 and b[1] + 8 <= n[0] - 1)
     assert (hiplib.fdtd_hip_fused_launch_count() > before) == fusable, name
 
