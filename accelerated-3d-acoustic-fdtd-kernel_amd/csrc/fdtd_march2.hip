@@ -489,6 +489,8 @@ struct RepairArgs {
   float *D;
   long sx;
   int sy, x_m, x_M, y_m, y_M, z_m, z_M;
+  int cx_m, cx_M;     // planes whose scattered cells count (the range, grown by 2 inside the domain)
+  int x_shift;        // source positions are in the coordinates of the whole domain
   int p_src_m, nsrc, coord_stride;
   float h_x, h_y, h_z, o_x, o_y, o_z;
   Coef2 k;
@@ -502,9 +504,9 @@ __global__ __launch_bounds__(256) void repair_kernel(RepairArgs a) {
   const float gx = (-a.o_x + a.coords[(long)p * a.coord_stride + 0]) / a.h_x;
   const float gy = (-a.o_y + a.coords[(long)p * a.coord_stride + 1]) / a.h_y;
   const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
-  const int tx = rx + (int)floorf(gx), ty = ry + (int)floorf(gy), tz = rz + (int)floorf(gz);
+  const int tx = rx + (int)floorf(gx) - a.x_shift, ty = ry + (int)floorf(gy), tz = rz + (int)floorf(gz);
   // corners outside the box were in memory before the sweep started: it has seen them
-  if (tx < a.x_m || tx > a.x_M || ty < a.y_m || ty > a.y_M || tz < a.z_m || tz > a.z_M) return;
+  if (tx < a.cx_m || tx > a.cx_M || ty < a.y_m || ty > a.y_M || tz < a.z_m || tz > a.z_M) return;
   // star cell: 0 = the corner's cell, 1..4 = x-2, x-1, x+1, x+2, then y, then z
   const int axis = star == 0 ? -1 : (star - 1) / 4, d = star == 0 ? 0 : ((star - 1) % 4 < 2 ? (star - 1) % 4 - 2 : (star - 1) % 4 - 1);
   const int x = tx + (axis == 0 ? d : 0), y = ty + (axis == 1 ? d : 0), z = tz + (axis == 2 ? d : 0);
@@ -719,10 +721,12 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   }
   const bool offsets_ok = xchunk <= addressable;
   // More than 8 sources: scatter and repair passes after the sweep work on the C level in memory,
-  // which holds the planes beside the range only when the range is the whole domain.
+  // which must then hold the two planes beside the range as well: the range ends where the domain
+  // does, or the caller asked for those planes to be kept (flags bits 2 and 3).
   const bool many = nsrc > M2_MAX_SRC;
+  const bool sides_in_memory = (g->x_m == dx_m || (flags & 4)) && (g->x_M == dx_M || (flags & 8));
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
-                    env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok && !(many && global_nx > 0) &&
+                    env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok && !(many && !sides_in_memory) &&
                     fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
                     (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g));
 
@@ -849,9 +853,10 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);
     }
   }
+  const int grown_lo = g->x_m - 2 > dx_m ? g->x_m - 2 : dx_m, grown_hi = g->x_M + 2 < dx_M ? g->x_M + 2 : dx_M;
   if (many) {   // the first scatter, on the C level in memory (corners inside the box; the others are there already)
     const int rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
-                                     x_shift, g->x_m + x_shift, g->x_M + x_shift, 2, gx_m, gx_M, stream);
+                                     x_shift, grown_lo + x_shift, grown_hi + x_shift, 2, gx_m, gx_M, stream);
     if (rc) return rc;
   }
   if (nzt > 1) {
@@ -873,6 +878,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     ra.C = next1; ra.B = cur; ra.m = m; ra.coords = src_coords; ra.D = next2;
     ra.sx = a.sx; ra.sy = a.sy;
     ra.x_m = g->x_m; ra.x_M = g->x_M; ra.y_m = g->y_m; ra.y_M = g->y_M; ra.z_m = g->z_m; ra.z_M = g->z_M;
+    ra.cx_m = grown_lo; ra.cx_M = grown_hi; ra.x_shift = x_shift;
     ra.p_src_m = p_src_m; ra.nsrc = nsrc; ra.coord_stride = coord_stride;
     ra.h_x = g->h_x; ra.h_y = g->h_y; ra.h_z = g->h_z; ra.o_x = g->o_x; ra.o_y = g->o_y; ra.o_z = g->o_z;
     ra.k = a.k;

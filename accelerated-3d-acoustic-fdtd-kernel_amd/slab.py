@@ -468,7 +468,7 @@ class HipStepper:
         if os.environ.get("FDTD_SLAB_OVERLAP", "1") == "0":
             return False
         if self.variant not in (-1, abi.VARIANTS["march2"]) or prop.nsrc > 8:
-            return False      # (with more than 8 sources the slab form of the call runs as two sweeps)
+            return False      # (more than 8 sources: the fused sweep needs the planes beside its range in memory)
         # the interior range of the split slab, as the library will see it
         nxp, nyp, nzp = prop.levels[0].shape
         g = abi.Geom(nxp, nyp, nzp, PAIR_GHOST, prop.nx - PAIR_GHOST - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1,

@@ -169,11 +169,18 @@ def pair_run(kind, name, outdir):
     U, m_loc = U.to(dev), m_loc.to(dev)
     src_t = None if c["src"] is None else torch.from_numpy(c["src"]).to(dev)
     coords_t = None if c["coords"] is None else torch.from_numpy(c["coords"]).to(dev)
-    stepper = OraclePairStepper(U) if kind == "oracle_pair" else pkg.slab.HipStepper(dev, variant=pkg.VARIANTS["auto"])
+    # FDTD_TEST_SLAB_VARIANT: kernel variant of the HIP stepper (march2 = fused sweep whatever the shape)
+    hip_variant = pkg.VARIANTS[os.environ.get("FDTD_TEST_SLAB_VARIANT", "auto")]
+    stepper = OraclePairStepper(U) if kind == "oracle_pair" else pkg.slab.HipStepper(dev, variant=hip_variant)
     comm = pkg.slab.TorchComm(dist, rank, world, stepper)
     prop = pkg.slab.SlabPairPropagator(layout, rank, [U[i] for i in range(4)], m_loc, src_t, coords_t, dt=dt, h=h,
                                        o=(0.0, 0.0, 0.0), stepper=stepper, comm=comm, time0=time_m)
     prop.run(time_m, time_M)
+    if kind == "hip_pair" and os.environ.get("FDTD_TEST_SLAB_VARIANT") == "march2" and time_M > time_m:
+        # the forced variant must have taken the fused sweep wherever rows are whole float4s
+        nz = U.shape[3] - 2 * HALO
+        took = pkg.lib().fdtd_hip_fused_launch_count() > 0
+        assert took == (nz % 4 == 0 and (nz // 4) % 64 != 1), (name, nz, took)
     # back into ring order; the shell travels with the level, padding further out stays with the slot
     out = torch.from_numpy(np.ascontiguousarray(u_loc)).clone()
     Uc = U.cpu()

@@ -98,6 +98,18 @@ def test_slab_pairs_hip_ranks_one_gpu(pkg, tmp_path, name, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("ricker30_n24_overlap", 2), ("noncubic_aniso", 2),
+                                        ("odd_sizes", 2)])
+def test_slab_pairs_forced_fused_hip_ranks_one_gpu(pkg, tmp_path, name, world, monkeypatch):
+    """The fused sweep forced on slabs of small and odd shapes: 27 and 30 sources (one call per rank over
+    its whole range, scatter and repair passes behind the sweep, ghost planes of u(t+1) kept), masked tiles
+    with the interior / boundary split, and a row length that is not a multiple of 4 (two-sweep fallback)."""
+    monkeypatch.setenv("FDTD_TEST_SLAB_VARIANT", "march2")
+    u = run_slabs("hip_pair", name, world, tmp_path, pkg)
+    check_against_golden(name, u, exact=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,world", [("ricker27_n32", 2), ("noncubic_aniso", 2), ("time_offset", 3),
                                         ("ricker30_n24_overlap", 2)])
 def test_slab_hip_two_ranks_one_gpu(pkg, tmp_path, name, world):
