@@ -324,13 +324,15 @@ class SlabPairPropagator:
         return self.stepper.mean_interior_kernel_ms()
 
 
-def init_rccl(device, rank=None, world=None):
+def init_rccl(device, rank=None, world=None, init_method=None):
     """Process group for the ghost messages: backend "nccl" (= RCCL), communicator created eagerly
     on `device`.  RCCL's stream keeps the default priority: with a high-priority stream the
     first exchange was seen to never complete on an MI355X (device-side wait that no kernel
     resolves), and the messages are hidden behind the interior sweep either way."""
     import torch.distributed as dist
     kw = {} if rank is None else {"rank": rank, "world_size": world}
+    if init_method is not None:      # e.g. "file:///path": rendezvous without a TCP port
+        kw["init_method"] = init_method
     dist.init_process_group("nccl", device_id=device, **kw)
     return dist
 

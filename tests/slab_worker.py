@@ -152,7 +152,9 @@ def pair_run(kind, name, outdir):
     """One rank of a two-steps-per-exchange run (kind: oracle_pair over gloo on the CPU, hip_pair
     with the HIP kernels, ghosts staged through the host)."""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's directory, which all ranks of a run share (no TCP port to collide on)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank,
+                            world_size=world)
     pkg = load_package()
     c = cases.build(name, pkg)
     kw = c["kw"]
@@ -215,7 +217,8 @@ def self_neighbour_run(name, outdir):
     pkg = load_package()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    pkg.slab.init_rccl(dev, 0, 1)
+    # one process: rendezvous through a file in the test's own directory (no TCP port to collide on)
+    pkg.slab.init_rccl(dev, 0, 1, init_method="file://" + os.path.join(outdir, "rendezvous"))
     c = cases.build(name, pkg)
     kw = c["kw"]
     h, dt = kw.get("h", (0.1, 0.1, 0.1)), kw.get("dt", 1e-3)
@@ -255,7 +258,8 @@ def self_neighbour_pair_run(name, outdir):
     pkg = load_package()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    pkg.slab.init_rccl(dev, 0, 1)
+    # one process: rendezvous through a file in the test's own directory (no TCP port to collide on)
+    pkg.slab.init_rccl(dev, 0, 1, init_method="file://" + os.path.join(outdir, "rendezvous"))
     c = cases.build(name, pkg)
     kw = c["kw"]
     h, dt = kw.get("h", (0.1, 0.1, 0.1)), kw.get("dt", 1e-3)
@@ -285,6 +289,12 @@ def self_neighbour_pair_run(name, outdir):
     a, b = (r.view(np.uint32) for r in results)
     nbad = int((a != b).sum())
     print(f"self-neighbour nccl pair run: {nbad} differing words")
+    if nbad:   # where: level and index ranges of the differing words
+        idx = np.argwhere(a != b)
+        for lvl in np.unique(idx[:, 0]):
+            sel = idx[idx[:, 0] == lvl]
+            print(f"  level {lvl}: {len(sel)} words, x {sel[:, 1].min()}..{sel[:, 1].max()} "
+                  f"y {sel[:, 2].min()}..{sel[:, 2].max()} z {sel[:, 3].min()}..{sel[:, 3].max()} (padded indices)")
     sys.exit(0 if nbad == 0 else 1)
 
 
@@ -297,7 +307,9 @@ def main():
     if kind in ("oracle_pair", "hip_pair"):
         return pair_run(kind, name, outdir)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's directory, which all ranks of a run share (no TCP port to collide on)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank,
+                            world_size=world)
     pkg = load_package()
     c = cases.build(name, pkg)
     kw = c["kw"]
