@@ -570,6 +570,12 @@ class HipStepper:
         rc = self.lib.fdtd_hip_copy_shell(C.byref(self.geom), self.lv_ptr[dst], self.lv_ptr[src], 0, self._sh[True])
         if rc:
             raise RuntimeError(f"fdtd_hip_copy_shell failed with hipError {rc}")
+        if self.split:
+            # the interior call adds the source corners that land in the halo layer of its own planes
+            # to this very shell: not before the copy has been through
+            ev = self.torch.cuda.Event()
+            ev.record(self.edge)
+            self.inner.wait_event(ev)
 
     def boundary_done(self):
         if self.split:

@@ -62,6 +62,11 @@ CASES = {
     # (corners at 511 | 512) and sit right beside it (corners at 510, 511)
     "fused_z1024": ("random", dict(n=(34, 16, 1024), nt=10, nsrc=3, h=(1.0, 1.1, 0.9), seed=26, edge_source=True,
                                    seam_sources=True)),
+    # a source above the last cell in z, half way along x: its upper corners land in the halo layer of planes
+    # in the middle of the grid (of the interior range of a slab, where the shell copy and the scatter of those
+    # corners are issued on different streams)
+    "fused_z512_zedge_source": ("random", dict(n=(36, 24, 512), nt=13, nsrc=2, h=(1.0, 1.0, 1.0), seed=27,
+                                               zedge_mid_source=True)),
     "warmup_only": ("ricker", dict(n=(16, 16, 16), nt=3, nsrc=1)),
     "no_sources_random": ("random", dict(n=(28, 20, 24), nt=8, nsrc=0, h=(1.0, 1.0, 1.0), seed=17)),
 }
@@ -106,6 +111,9 @@ def build(name, pkg):
         if p.get("edge_source"):
             # a source in the outermost cell: its scatter reaches the first halo layer
             coords[0] = np.array([(nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2]],
+                                 dtype=np.float32)
+        if p.get("zedge_mid_source"):
+            coords[1] = np.array([0.5 * (nx - 1) * h[0] + 0.2 * h[0], 0.4 * (ny - 1) * h[1], (nz - 1) * h[2] + 0.3 * h[2]],
                                  dtype=np.float32)
         if p.get("seam_sources"):
             coords[1, 2] = np.float32(511.5 * h[2])

@@ -89,7 +89,7 @@ def test_slab_pairs_edges_first_orchestration_cpu(pkg, tmp_path, name, world, mo
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,world", [("fused_z512", 2), ("fused_z512_edge_source", 2), ("fused_z512_ricker8", 3),
-                                        ("ricker27_n32", 2), ("fused_z1024", 2)])
+                                        ("ricker27_n32", 2), ("fused_z1024", 2), ("fused_z512_zedge_source", 2)])
 def test_slab_pairs_hip_ranks_one_gpu(pkg, tmp_path, name, world):
     """The fused sweep inside the slab schedule (512-wide cases: boundary and interior calls on two
     streams) and the two-sweep fallback (32^3), ranks sharing one GPU."""
@@ -134,7 +134,8 @@ def test_slab_rccl_schedule_one_gpu(pkg, tmp_path, name, march):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,zone_fused", [("fused_z512", "0"), ("fused_z512_edge_source", "0"),
                                              ("fused_z512_ricker8", "0"), ("fused_z1024", "0"),
-                                             ("fused_z512_edge_source", "1"), ("fused_z1024", "1")])
+                                             ("fused_z512_edge_source", "1"), ("fused_z1024", "1"),
+                                             ("fused_z512_zedge_source", "0"), ("fused_z512_zedge_source", "1")])
 def test_slab_pairs_rccl_schedule_one_gpu(pkg, tmp_path, name, zone_fused):
     """Two steps per exchange with real RCCL messages (4 planes per side and pair) next to the fused
     interior sweep, one rank as its own two neighbours; bit-identical to the CPU orchestration.  The
