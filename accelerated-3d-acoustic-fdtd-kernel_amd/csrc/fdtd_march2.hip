@@ -626,13 +626,15 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
 // Does the automatic choice take the fused kernel for an eligible problem?  At least
 // FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of u(time+1)
 // each chunk recomputes.  Tiles filled to at least FDTD_FUSE2_MIN_FILL percent (80): the fused sweep
-// is about 1.25 times as fast as the marching kernel per cell it spans.  And not a single row of 256
-// cells: such a grid sits in the last-level cache, where the marching kernel was the faster one
-// (256^3: 300 against 253 Gcells/s); that one is fused only on explicit request.
+// is about 1.25 times as fast as the marching kernel per cell it spans.  Rows of 256 cells or less
+// only from 32 M cells on: a smaller grid of that kind sits in the last-level cache, where the
+// marching kernel was the faster one (256^3: 300 against 253 Gcells/s; 512 x 512 x 256: 320 against
+// 403 for the fused sweep).
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   const M2Tiling t = m2_tiling(ey, ez);
-  return (t.wide || ez > M2_ZCELLS) && 100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 80) &&
+  const bool big = (long)ex * ey * ez >= 32L * 1000 * 1000;
+  return (t.wide || ez > M2_ZCELLS || big) && 100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 80) &&
          ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 

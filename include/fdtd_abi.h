@@ -171,8 +171,9 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * hipErrorInvalidValue): unlike the reference's ring, u(time+2) cannot be written over
  * u(time-1), because neighbouring workgroups still read it.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
  * the fusion, any other variant selects the single-step kernel used for both sweeps.
- * FDTD_VARIANT_MARCH2 fuses whatever the x range and the fill, and also at a z extent of
- * 256 or less (AUTO leaves those to the single-step kernel, which is faster there). */
+ * FDTD_VARIANT_MARCH2 fuses whatever the x range and the fill, and also small grids with a z
+ * extent of 256 or less (below 32 M cells AUTO leaves those to the single-step kernel, which
+ * is faster there). */
 int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
                        const float *src_coords, const float *cur, const float *prev,
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,

@@ -53,7 +53,8 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     ((640, 640, 640), 1, "auto", 1),      # 83 %
     ((384, 384, 384), 1, "auto", 0),      # 75 %: left to the marching kernel ...
     ((384, 384, 384), 1, "march2", 1),    # ... unless asked for
-    ((256, 256, 256), 1, "auto", 0),      # a single row of 256 cells
+    ((256, 256, 256), 1, "auto", 0),      # rows of 256 cells in a grid that fits the last-level cache
+    ((512, 512, 256), 1, "auto", 1),      # ... and in one that does not
     ((256, 256, 256), 1, "march2", 1),
     ((20, 512, 512), 1, "auto", 0),       # fewer than 32 planes
     ((20, 512, 512), 1, "march2", 1),
