@@ -626,16 +626,19 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
 // Does the automatic choice take the fused kernel for an eligible problem?  At least
 // FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of u(time+1)
 // each chunk recomputes.  Tiles filled to at least FDTD_FUSE2_MIN_FILL percent (80): the fused sweep
-// is about 1.25 times as fast as the marching kernel per cell it spans.  Rows of 256 cells or less
-// only from 32 M cells on: a smaller grid of that kind sits in the last-level cache, where the
-// marching kernel was the faster one (256^3: 300 against 253 Gcells/s; 512 x 512 x 256: 320 against
-// 403 for the fused sweep).
+// is about 1.25 times as fast as the marching kernel per cell it spans.  At least
+// FDTD_FUSE2_MIN_CELLS (12 M) cells, 32 M with rows of 256 cells or less: smaller grids sit in the
+// last-level cache and have too few tiles to fill the device, and the marching kernel is the faster
+// one there (128 x 128 x 512: 286 against 205 Gcells/s, 256^3: 300 against 253; but 64 x 512 x 512:
+// 333 against 358 for the fused sweep, 512 x 512 x 256: 320 against 403).
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   const M2Tiling t = m2_tiling(ey, ez);
-  const bool big = (long)ex * ey * ez >= 32L * 1000 * 1000;
-  return (t.wide || ez > M2_ZCELLS || big) && 100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 80) &&
-         ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
+  const long cells = (long)ex * ey * ez;
+  const long min_cells = env_int2("FDTD_FUSE2_MIN_CELLS", 12000000);
+  const long min_cells_short_rows = min_cells > 0 ? (min_cells > 32000000 ? min_cells : 32000000) : 0;
+  return cells >= ((t.wide || ez > M2_ZCELLS) ? min_cells : min_cells_short_rows) &&
+         100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 80) && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 
 // Two steps (time, time + 1) on four level buffers: cur = u(time), prev = u(time-1) are read,

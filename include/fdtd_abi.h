@@ -162,7 +162,7 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * u(time+1) and next2 = u(time+2) are written (interior cells only; the halo cells of
  * next1 and next2 keep their values and are read as such).  Both source scatters are
  * included.  When the shape allows (z extent a multiple of 4, at least 8 rows; under
- * FDTD_VARIANT_AUTO also: at least 32 planes and a cross-section that fills the sweep's tiles of
+ * FDTD_VARIANT_AUTO also: at least 32 planes, 12 M cells and a cross-section that fills the sweep's tiles of
  * 8 rows x 512 cells, or 16 x 256, to 80 %) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
  * per cell update; otherwise they run one after the other.  Either way the result is
  * bit for bit that of two single steps.  This is the time fusion the reference driver

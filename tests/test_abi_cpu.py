@@ -56,6 +56,8 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     ((256, 256, 256), 1, "auto", 0),      # rows of 256 cells in a grid that fits the last-level cache
     ((512, 512, 256), 1, "auto", 1),      # ... and in one that does not
     ((256, 256, 256), 1, "march2", 1),
+    ((128, 128, 512), 1, "auto", 0),      # fewer than 12 M cells
+    ((64, 512, 512), 1, "auto", 1),
     ((20, 512, 512), 1, "auto", 0),       # fewer than 32 planes
     ((20, 512, 512), 1, "march2", 1),
     ((64, 64, 516), 1, "march2", 0),      # a row ending on the first float4 of a wave
