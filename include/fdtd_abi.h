@@ -161,19 +161,19 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * nxp*nyp*nzp floats each: cur = u(time) and prev = u(time-1) are read, next1 =
  * u(time+1) and next2 = u(time+2) are written (interior cells only; the halo cells of
  * next1 and next2 keep their values and are read as such).  Both source scatters are
- * included.  When the shape allows (z extent a multiple of 4, at least 8 rows; under
- * FDTD_VARIANT_AUTO also: at least 32 planes, 12 M cells and a cross-section that fills the sweep's tiles of
- * 8 rows x 512 cells, or 16 x 256, to 80 %) the two sweeps are fused into one kernel that moves 10 instead of 16 bytes
- * per cell update; otherwise they run one after the other.  Either way the result is
- * bit for bit that of two single steps.  This is the time fusion the reference driver
- * has a knob for (t_fuse, main.cpp:261,267) and no reference kernel implements.
+ * included.  When the shape allows (z extent a multiple of 4, at least 8 rows) the two
+ * sweeps are fused into one kernel that moves 10 instead of 16 bytes per cell update;
+ * otherwise they run one after the other.  Either way the result is bit for bit that of
+ * two single steps.  This is the time fusion the reference driver has a knob for
+ * (t_fuse, main.cpp:261,267) and no reference kernel implements.
  * next1 and next2 must not overlap each other, cur, prev or m (refused with
  * hipErrorInvalidValue): unlike the reference's ring, u(time+2) cannot be written over
- * u(time-1), because neighbouring workgroups still read it.  variant: FDTD_VARIANT_AUTO or FDTD_VARIANT_MARCH2 allow
- * the fusion, any other variant selects the single-step kernel used for both sweeps.
- * FDTD_VARIANT_MARCH2 fuses whatever the x range and the fill, and also small grids with a z
- * extent of 256 or less (below 32 M cells AUTO leaves those to the single-step kernel, which
- * is faster there). */
+ * u(time-1), because neighbouring workgroups still read it.
+ * variant: FDTD_VARIANT_AUTO fuses boxes of at least 32 planes and 12 M cells (32 M with
+ * rows of 256 cells or less) whose cross-section fills the sweep's tiles of 8 rows x 512
+ * cells, or 16 x 256, to 80 %: below that the single-step kernel is as fast or faster.
+ * FDTD_VARIANT_MARCH2 fuses every shape the kernel takes.  Any other variant selects the
+ * single-step kernel used for both sweeps. */
 int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *src,
                        const float *src_coords, const float *cur, const float *prev,
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,
@@ -191,10 +191,12 @@ long fdtd_hip_fused_launch_count(void);
  * operators and fdtd_hip_time_loop use on small grids) this process has issued so far. */
 long fdtd_hip_small_step_count(void);
 
-/* The same with two extras for callers that measure or know more: ev_begin / ev_end
- * (hipEvent_t, may be NULL) are recorded right before the first and right after the last
- * sweep kernel; flags bit 0 (FDTD_TWO_STEPS_SOURCES_INSIDE) promises that no source corner
- * lands in the halo layer, which saves the two small launches that serve such corners. */
+/* The same with two extras for callers that measure or know more.  ev_begin / ev_end
+ * (hipEvent_t, may be NULL): when the call is a single sweep launch they receive the start
+ * and stop times of that dispatch itself, otherwise they are recorded on the stream before
+ * the first and after the last launch of the call.  flags bit 0
+ * (FDTD_TWO_STEPS_SOURCES_INSIDE) promises that no source corner lands in the halo layer,
+ * which saves the two small launches that serve such corners. */
 #define FDTD_TWO_STEPS_SOURCES_INSIDE 1
 int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float *src,
                           const float *src_coords, const float *cur, const float *prev,
