@@ -193,7 +193,7 @@ def main():
             return fn(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
 
         # two steps per sweep where the library takes the fused sweep for this box
-        fused = (not h16) and bool(L.fdtd_hip_two_steps_fuses(C.byref(g), 1, variant))
+        fused = (not h16) and K >= 2 and bool(L.fdtd_hip_two_steps_fuses(C.byref(g), 1, variant))
         updates_per_launch = 1
         if fused:
             # Two steps per sweep: four level buffers rotate (the three ring slots and one more).  All
