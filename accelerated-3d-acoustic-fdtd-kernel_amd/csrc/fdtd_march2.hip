@@ -125,12 +125,13 @@ __device__ __forceinline__ f32x2 update_pair(const Coef2 &k, f32x2 uc, f32x2 xm2
   return f32x2{num.x / mc.x, num.y / mc.y};
 }
 // edge_r: this lane's right neighbours are eR even though it is not lane 63 (the last lane of a row
-// that ends inside the wave).
+// that ends inside the wave).  offer: what this lane shows the lane before it as cells 0 and 1
+// (its own c.x, c.y, except in the lane behind a row that ends on lane 0 of a wave).
 __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, f32x4 xm1, f32x4 xp1, f32x4 xp2,
                                             f32x4 ym2, f32x4 ym1, f32x4 yp1, f32x4 yp2, f32x2 eL, f32x2 eR, f32x4 up,
-                                            f32x4 mc, bool edge_r = false) {
+                                            f32x4 mc, bool edge_r, f32x2 offer) {
   const f32x2 l = f32x2{dpp_prev(eL.x, c.z), dpp_prev(eL.y, c.w)};   // cells z-2, z-1 of cell 0
-  f32x2 r = f32x2{dpp_next(eR.x, c.x), dpp_next(eR.y, c.y)};         // cells z+1, z+2 of cell 3
+  f32x2 r = f32x2{dpp_next(eR.x, offer.x), dpp_next(eR.y, offer.y)}; // cells z+1, z+2 of cell 3
   r = edge_r ? eR : r;
   const f32x2 cl = lo2(c), ch = hi2(c);
   // cells 0,1: z-2: (l.x, l.y)  z+2: (c.z, c.w)   z-1: (l.y, c.x)  z+1: (c.y, c.z)
@@ -183,7 +184,12 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   // of float4 `nvalid` (the four halo cells behind the row) and store nothing
   const int nvalid = MASK ? min(64 * ZH, (a.z_M + 1 - zb) >> 2) : 64 * ZH;
   const bool lane_valid = !MASK || lz < nvalid;
-  const bool last_valid = MASK && lz == nvalid - 1;        // its right neighbours come from the edge loads
+  // The last lane inside the row takes its right neighbours from the edge loads.  When that lane
+  // is lane 0 of its wave the edge loads are taken by its left neighbours; lane 1, which sits on
+  // the halo cells behind the row, then shows it those: its B registers hold them anyway, and for
+  // the C level it loads them from memory in place of its edge cells (offers_halo).
+  const bool last_valid = MASK && lz == nvalid - 1 && lane != 0;
+  const bool offers_halo = MASK && lz == nvalid && lane == 1;
   const bool edge_hi = (lane == 63 && lane_valid) || last_valid;
   // the row ends in this wave or before it: nothing to the right of the wave comes from LDS
   const bool row_ends_here = MASK && nvalid <= (ZH == 2 ? (h + 1) * 64 : 64);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const unsigned vz0 = (unsigned)(zb + (lz - lane) * 4 + FDTD_HALO) * 4u;   // lane 0 of this wave
   const unsigned vz = (unsigned)(zb + (MASK ? min(lz, nvalid) : lz) * 4 + FDTD_HALO) * 4u;
   const unsigned vze = edge_hi ? vz + 16u : vz - 8u;
-  const unsigned vzc = edge_hi ? vz + 16u : vz0 - 8u;
+  const unsigned vzc = edge_hi ? vz + 16u : (offers_halo ? vz : vz0 - 8u);
   int rowoff[3];   // byte offset of the segment's row inside a plane (MASK: rows clamped to the array)
 #pragma unroll
   for (int s = 0; s < 3; ++s) rowoff[s] = ((MASK ? min(yrow[s], a.y_M + 4) : yrow[s]) + FDTD_HALO) * a.sy * 4;
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
         const f32x4 ym2 = Bbuf[buf][r][lc], ym1 = Bbuf[buf][r + 1][lc];
         const f32x4 yp1 = Bbuf[buf][r + 3][lc], yp2 = Bbuf[buf][r + 4][lc];
         cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
-                          mv[s], last_valid);
+                          mv[s], last_valid, lo2(PB(2)[s]));
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
         if constexpr (MASK && s < 2) cnew = (s == 0 ? out0 : out1) ? av[s] : cnew;
         if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
             else if (!row_ends_here) eR = f32x2{nb.x, nb.y};
           }
           f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
-                               PB(0)[s], mh[0][s], last_valid);
+                               PB(0)[s], mh[0][s], last_valid, offers_halo ? ce[s] : lo2(PC(2)[s]));
           if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
           if (!row_out) {
             if (lane_valid) st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vz, o);
@@ -608,9 +614,6 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   // rows of whole float4s, at least one tile's worth of rows
   if (ex < 1 || ez < 4 || ez % 4 || ey < M2_ROWS) return false;
-  // a row that ends with the first float4 of a wave would make that lane both the first and the last
-  // of its wave, and a lane holds the edge cells of one side only
-  if (((ez >> 2) & 63) == 1) return false;
   if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
   if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
   if (((long)g->nyp * g->nzp) % 4) return false;

@@ -182,7 +182,7 @@ def pair_run(kind, name, outdir):
         # the forced variant must have taken the fused sweep wherever rows are whole float4s
         nz = U.shape[3] - 2 * HALO
         took = pkg.lib().fdtd_hip_fused_launch_count() > 0
-        assert took == (nz % 4 == 0 and (nz // 4) % 64 != 1), (name, nz, took)
+        assert took == (nz % 4 == 0), (name, nz, took)
     # back into ring order; the shell travels with the level, padding further out stays with the slot
     out = torch.from_numpy(np.ascontiguousarray(u_loc)).clone()
     Uc = U.cpu()
