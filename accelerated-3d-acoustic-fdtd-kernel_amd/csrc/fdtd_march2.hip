@@ -612,8 +612,8 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
                           const float *c, const float *d, int nsrc) {
   if (!g) return false;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
-  // rows of whole float4s, at least one tile's worth of rows
-  if (ex < 1 || ez < 4 || ez % 4 || ey < M2_ROWS) return false;
+  // rows of whole float4s
+  if (ex < 1 || ez < 4 || ez % 4 || ey < 1) return false;
   if (g->nzp % 4 || g->z_m % 4 || g->z_m < 0) return false;
   if ((((uintptr_t)m | (uintptr_t)b | (uintptr_t)a_prev | (uintptr_t)c | (uintptr_t)d) % 16) != 0) return false;
   if (((long)g->nyp * g->nzp) % 4) return false;

@@ -161,7 +161,7 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * nxp*nyp*nzp floats each: cur = u(time) and prev = u(time-1) are read, next1 =
  * u(time+1) and next2 = u(time+2) are written (interior cells only; the halo cells of
  * next1 and next2 keep their values and are read as such).  Both source scatters are
- * included.  When the shape allows (z extent a multiple of 4, at least 8 rows) the two
+ * included.  When the shape allows (z extent a multiple of 4) the two
  * sweeps are fused into one kernel that moves 10 instead of 16 bytes per cell update;
  * otherwise they run one after the other.  Either way the result is bit for bit that of
  * two single steps.  This is the time fusion the reference driver has a knob for

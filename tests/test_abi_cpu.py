@@ -62,7 +62,7 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     ((20, 512, 512), 1, "march2", 1),
     ((64, 64, 516), 1, "march2", 1),      # a row ending on the first float4 of a wave
     ((64, 64, 514), 1, "march2", 0),      # rows that are not whole float4s
-    ((64, 7, 512), 1, "march2", 0),       # fewer than 8 rows
+    ((64, 7, 512), 1, "march2", 1),       # fewer than 8 rows: one masked tile
     ((512, 512, 512), 27, "auto", 1),     # more than 8 sources: fused as well (scatter and repair passes behind the sweep)
     ((512, 512, 512), 8, "auto", 1),
     ((512, 512, 512), 1, "march", 0),     # a single-step variant by name

@@ -234,7 +234,9 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((40, 24, 512), 20, "auto"), ((36, 20, 1024), 11, "auto"),
                                                 ((24, 8, 516), 2, "march2"), ((24, 8, 260), 2, "march2"),
                                                 ((24, 16, 516), 3, "march2"), ((40, 100, 772), 2, "march2"),
-                                                ((20, 24, 4), 1, "march2")])
+                                                ((20, 24, 4), 1, "march2"), ((24, 5, 512), 2, "march2"),
+                                                ((24, 1, 256), 1, "march2"), ((30, 3, 520), 2, "march2"),
+                                                ((24, 2, 1028), 2, "march2")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant, monkeypatch):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
@@ -243,7 +245,7 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
     of 1024, 1536 and 768 cells (two and three z-tiles of 512, three of 256; the cells around the cuts
     are redone by the seam pass); a full cross-section of 256 tiles in three launches; and cross-sections
     that do not fill their tiles (rows ending inside a z-tile, inside the first half of one, eight cells into
-    one; fewer than 8 or 16 rows in the last y-tile; rows that end on the first float4 of a wave, in the
+    one; fewer than 8 or 16 rows in the last y-tile, or in the whole box; rows that end on the first float4 of a wave, in the
     second wave of a 512-cell tile, in a z-tile of its own, in both tilings; rows of 4 cells), which run
     the masked variant of the kernel."""
     import torch
@@ -358,7 +360,7 @@ def test_two_steps_rejects_overlapping_levels(pkg, hiplib):
 
 @pytest.mark.parametrize("name", list(cases.CASES))
 def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, monkeypatch):
-    """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s and at least 8 rows goes
+    """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s goes
     through the two-step sweep (masked tiles for all but the fused_z* shapes; with 27 and 30 sources the
     scatter and repair passes behind the sweep), the others through the ordinary loop; the bytes are the
     fixture's either way."""
@@ -374,7 +376,7 @@ def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, monkeypatch):
     time_M = c["kw"].get("time_M", None if c["src"] is None else c["src"].shape[0] - 1)
     n_steps = time_M - c["kw"].get("time_m", 0) + 1
     lo, hi = c["kw"].get("p_src", (0, (c["coords"].shape[0] if c["coords"] is not None else 0) - 1))
-    fusable = (ex >= 1 and ey >= 8 and ez % 4 == 0 and b[4] % 4 == 0 and n_steps >= 4
+    fusable = (ex >= 1 and ey >= 1 and ez % 4 == 0 and b[4] % 4 == 0 and n_steps >= 4
                and b[5] + 8 <= n[2] - 1 and b[3] + 8 <= n[1] - 1 and b[1] + 8 <= n[0] - 1)
     assert (hiplib.fdtd_hip_fused_launch_count() > before) == fusable, name
 
