@@ -628,20 +628,18 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
 
 // Does the automatic choice take the fused kernel for an eligible problem?  At least
 // FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of u(time+1)
-// each chunk recomputes.  Tiles filled to at least FDTD_FUSE2_MIN_FILL percent (80): the fused sweep
-// is about 1.25 times as fast as the marching kernel per cell it spans.  At least
-// FDTD_FUSE2_MIN_CELLS (12 M) cells, 32 M with rows of 256 cells or less: smaller grids sit in the
+// each chunk recomputes.  At least FDTD_FUSE2_MIN_CELLS (12 M) cells: smaller grids sit in the
 // last-level cache and have too few tiles to fill the device, and the marching kernel is the faster
-// one there (128 x 128 x 512: 286 against 205 Gcells/s, 256^3: 300 against 253; but 64 x 512 x 512:
-// 333 against 358 for the fused sweep, 512 x 512 x 256: 320 against 403).
+// one there (192^3: 190 against 150 Gcells/s, 224^3: 233 against 223; from 240^3 on the fused sweep
+// wins: 242 against 262, 256^3: 301 against 325, 64 x 512 x 512: 333 against 358).  Tiles filled to
+// at least FDTD_FUSE2_MIN_FILL percent (50): the lowest fill measured is 50 % (260^3: 175 against 216
+// Gcells/s; the marching kernel pads such rows too), below that nothing is known.
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   const M2Tiling t = m2_tiling(ey, ez);
   const long cells = (long)ex * ey * ez;
-  const long min_cells = env_int2("FDTD_FUSE2_MIN_CELLS", 12000000);
-  const long min_cells_short_rows = min_cells > 0 ? (min_cells > 32000000 ? min_cells : 32000000) : 0;
-  return cells >= ((t.wide || ez > M2_ZCELLS) ? min_cells : min_cells_short_rows) &&
-         100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 80) && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
+  return cells >= env_int2("FDTD_FUSE2_MIN_CELLS", 12000000) &&
+         100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 50) && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 
 // Two steps (time, time + 1) on four level buffers: cur = u(time), prev = u(time-1) are read,
@@ -751,7 +749,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // One sweep launch and nothing else: the two events take the start and stop times of that
   // dispatch itself (what a profiler reports as the kernel's duration); otherwise they are
   // recorded on the stream around everything the call launches.
-  const int per_launch = env_int2("FDTD_FUSE2_WGS", ntile > 256 ? ntile : 256);
+  const int per_launch = env_int2("FDTD_FUSE2_WGS", 256);
   const bool dispatch_times = fuse && ev_begin && ev_end && nzt == 1 && !many &&
                               (long)ntile * ((ex + xchunk - 1) / xchunk) <= per_launch;
   if (ev_begin && !dispatch_times) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
@@ -837,8 +835,9 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     const long chunks = (ex + xchunk - 1) / xchunk;
     if ((long)ntile * chunks > 0x7fffffffL) return (int)hipErrorInvalidValue;
     const long total = (long)ntile * chunks;
-    // (per_launch: a cross-section of more than 256 tiles goes into one launch whole: with the tiles of
-    // one chunk spread over several launches the 256 x 2048 x 2048 slab ran at 323 instead of 371 Gcells/s)
+    // (per_launch: one round of 256 workgroups whatever the number of tiles of a cross-section.  Whole
+    // cross-sections per launch leave a partly filled last round when their tile count is not a
+    // multiple of 256: 1536^3, 576 tiles, ran at 342 instead of 480 Gcells/s, 1032^3 at 245 instead of 346.)
     for (long base = 0; base < total; base += per_launch) {
       const dim3 grid((unsigned)(total - base < per_launch ? total - base : per_launch)), block(512);
       const int b = (int)base;

@@ -51,12 +51,12 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     ((768, 768, 768), 1, "auto", 1),      # three z-tiles of 256
     ((500, 500, 500), 1, "auto", 1),      # masked tiles, 97 % full
     ((640, 640, 640), 1, "auto", 1),      # 83 %
-    ((384, 384, 384), 1, "auto", 0),      # 75 %: left to the marching kernel ...
-    ((384, 384, 384), 1, "march2", 1),    # ... unless asked for
-    ((256, 256, 256), 1, "auto", 0),      # rows of 256 cells in a grid that fits the last-level cache
-    ((512, 512, 256), 1, "auto", 1),      # ... and in one that does not
-    ((256, 256, 256), 1, "march2", 1),
-    ((128, 128, 512), 1, "auto", 0),      # fewer than 12 M cells
+    ((384, 384, 384), 1, "auto", 1),      # 75 %
+        ((256, 256, 256), 1, "auto", 1),      # rows of 256 cells
+    ((260, 260, 260), 1, "auto", 1),      # tiles half empty
+    ((1024, 256, 68), 1, "auto", 0),      # 27 %: left to the marching kernel ...
+    ((1024, 256, 68), 1, "march2", 1),    # ... unless asked for
+        ((128, 128, 512), 1, "auto", 0),      # fewer than 12 M cells
     ((64, 512, 512), 1, "auto", 1),
     ((20, 512, 512), 1, "auto", 0),       # fewer than 32 planes
     ((20, 512, 512), 1, "march2", 1),
