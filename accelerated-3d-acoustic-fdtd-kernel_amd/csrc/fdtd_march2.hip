@@ -28,8 +28,7 @@
 // Shapes: tiles of 8 rows x 512 cells, or of 16 rows x 256 cells (the workgroup then carries two
 // 8-row tiles of 256-cell rows, one per wave parity), whichever the cross-section fills better; a
 // cross-section that does not fill its tiles runs the MASK instantiation.  Rows must be whole
-// float4s and there must be at least 8 of them; anything else is run as two single sweeps by
-// fdtd_hip_two_steps.  Up to 8 sources are scattered by the sweep itself, more by passes behind
+// float4s; anything else is run as two single sweeps by fdtd_hip_two_steps.  Up to 8 sources are scattered by the sweep itself, more by passes behind
 // it (repair_kernel).
 // Longer rows are cut into z-tiles of 512 (or 256) cells.  A tile cannot know its neighbour's C
 // beyond the cut in time, so the four D cells around every cut (two on either side) come out wrong
