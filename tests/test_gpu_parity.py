@@ -236,7 +236,8 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((24, 16, 516), 3, "march2"), ((40, 100, 772), 2, "march2"),
                                                 ((20, 24, 4), 1, "march2"), ((24, 5, 512), 2, "march2"),
                                                 ((24, 1, 256), 1, "march2"), ((30, 3, 520), 2, "march2"),
-                                                ((24, 2, 1028), 2, "march2")])
+                                                ((24, 2, 1028), 2, "march2"), ((30, 20, 516), 12, "march2"),
+                                                ((24, 5, 260), 10, "march2")])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant, monkeypatch):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
