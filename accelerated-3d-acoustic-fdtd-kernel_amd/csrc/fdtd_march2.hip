@@ -627,17 +627,18 @@ bool fdtd_march2_eligible(const struct fdtd_geom *g, const float *m, const float
 
 // Does the automatic choice take the fused kernel for an eligible problem?  At least
 // FDTD_FUSE2_MIN_PLANES (32) planes: thinner ranges spend too much on the four planes of u(time+1)
-// each chunk recomputes.  At least FDTD_FUSE2_MIN_CELLS (12 M) cells: smaller grids sit in the
+// each chunk recomputes.  At least FDTD_FUSE2_MIN_CELLS (16 M) cells: smaller grids sit in the
 // last-level cache and have too few tiles to fill the device, and the marching kernel is the faster
-// one there (192^3: 190 against 150 Gcells/s, 224^3: 233 against 223; from 240^3 on the fused sweep
-// wins: 242 against 262, 256^3: 301 against 325, 64 x 512 x 512: 333 against 358).  Tiles filled to
+// one there (192^3: 190 against 150 Gcells/s, 224^3: 233 against 223, 48 x 512 x 512: 340 against
+// 276, 160 x 160 x 512: 317 against 286; the two cross between 13 M and 17 M cells: 240^3 242 against
+// 262, 64 x 512 x 512 351 against 344, 256^3 301 against 325, 192 x 192 x 512 333 against 349).  Tiles filled to
 // at least FDTD_FUSE2_MIN_FILL percent (50): the lowest fill measured is 50 % (260^3: 175 against 216
 // Gcells/s; the marching kernel pads such rows too), below that nothing is known.
 bool fdtd_march2_preferred(const struct fdtd_geom *g) {
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   const M2Tiling t = m2_tiling(ey, ez);
   const long cells = (long)ex * ey * ez;
-  return cells >= env_int2("FDTD_FUSE2_MIN_CELLS", 12000000) &&
+  return cells >= env_int2("FDTD_FUSE2_MIN_CELLS", 16000000) &&
          100.0 * t.fill >= env_int2("FDTD_FUSE2_MIN_FILL", 50) && ex >= env_int2("FDTD_FUSE2_MIN_PLANES", 32);
 }
 

@@ -169,7 +169,7 @@ int fdtd_hip_source_inject_slab(const struct fdtd_geom *g, const float *m,
  * next1 and next2 must not overlap each other, cur, prev or m (refused with
  * hipErrorInvalidValue): unlike the reference's ring, u(time+2) cannot be written over
  * u(time-1), because neighbouring workgroups still read it.
- * variant: FDTD_VARIANT_AUTO fuses boxes of at least 32 planes and 12 M cells whose
+ * variant: FDTD_VARIANT_AUTO fuses boxes of at least 32 planes and 16 M cells whose
  * cross-section fills the sweep's tiles of 8 rows x 512 cells, or 16 x 256, to 50 %: smaller
  * boxes are faster with the single-step kernel, emptier tiles have not been measured.
  * FDTD_VARIANT_MARCH2 fuses every shape the kernel takes.  Any other variant selects the

@@ -56,7 +56,7 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     ((260, 260, 260), 1, "auto", 1),      # tiles half empty
     ((1024, 256, 68), 1, "auto", 0),      # 27 %: left to the marching kernel ...
     ((1024, 256, 68), 1, "march2", 1),    # ... unless asked for
-        ((128, 128, 512), 1, "auto", 0),      # fewer than 12 M cells
+        ((128, 128, 512), 1, "auto", 0),      # fewer than 16 M cells
     ((64, 512, 512), 1, "auto", 1),
     ((20, 512, 512), 1, "auto", 0),       # fewer than 32 planes
     ((20, 512, 512), 1, "march2", 1),

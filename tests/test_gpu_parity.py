@@ -330,7 +330,7 @@ def test_small_grid_time_loop(pkg, hiplib, name):
         pos = np.floor(c["coords"][lo:hi + 1].astype(np.float32) / h).astype(int)
         for d in range(3):
             inside &= bool(np.all(pos[:, d] >= b[2 * d]) and np.all(pos[:, d] + 1 <= b[2 * d + 1]))
-    expected = inside and not (empty or p.get("nsrc", 0) > 16)   # (all fixture grids are below 12 M cells)
+    expected = inside and not (empty or p.get("nsrc", 0) > 16)   # (all fixture grids are below 16 M cells)
     assert hiplib.fdtd_hip_small_step_count() - before == (n_steps if expected else 0), name
     assert (prof.section0 > 0) == (n_steps > pkg.WARMUP_STEPS)
 
