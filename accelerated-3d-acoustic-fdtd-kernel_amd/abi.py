@@ -10,6 +10,7 @@ import numpy as np
 
 HALO = 4            # main.cpp:32, cuda.cu:55
 WARMUP_STEPS = 5    # openacc.cpp:5
+STATIC_SCRATCH_FLOATS = 4 << 20   # FDTD_STATIC_SCRATCH_FLOATS of fdtd_abi.h
 VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "march2": 5, "auto": -1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -102,6 +103,9 @@ def lib():
     L.fdtd_hip_two_steps_slab.argtypes = ([C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 9
                                           + [C.c_void_p, C.c_long, C.c_void_p])
     L.fdtd_hip_two_steps_slab.restype = C.c_int
+    L.fdtd_hip_two_steps_slab_noalloc.argtypes = ([C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 9
+                                                  + [C.c_void_p])
+    L.fdtd_hip_two_steps_slab_noalloc.restype = C.c_int
     L.fdtd_hip_one_step_slab.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_void_p]
     L.fdtd_hip_one_step_slab.restype = C.c_int
     L.fdtd_hip_fused_launch_count.argtypes = []

@@ -36,7 +36,9 @@
 // then runs as a launch of its own after that.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 #include "fdtd_device.h"
@@ -930,6 +932,62 @@ extern "C" int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
                              coord_stride, variant, flags, x_shift, global_nx, stream, nullptr, nullptr, scratch,
                              scratch_floats);
+}
+
+// Allocation-free form of fdtd_hip_two_steps_slab for callers that cannot allocate device memory
+// (HIP graph capture, serving loops, harnesses that forbid hipMalloc).  The work space of the
+// two-sweep path — u(time+1) on the range grown by two planes — lives in a file-scope device
+// array instead of a caller buffer.  Every GPU holds its own copy of that array at its own
+// address (16 MiB per GPU from the moment the library's code object is loaded there until the
+// process ends); the address is looked up once per device, with that device current, and from
+// then on only that pointer is used: in host code the array's name is not a device address.
+// The array keeps the previous call's contents; the path overwrites all (ex + 4) planes it reads
+// before it reads them, so nothing has to be cleared.  Calls that overlap in time on one GPU
+// share the array and race.
+static __device__ __align__(256) float static_scratch[FDTD_STATIC_SCRATCH_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+float *g_static_scratch_ptr[kMaxDevices] = {};
+std::mutex g_static_scratch_mutex;
+
+// Device address of static_scratch on the current device (looked up at the first call there).
+int static_scratch_on_current_device(float **out) {
+  int dev = -1;
+  FDTD_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return (int)hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+  if (!g_static_scratch_ptr[dev]) {
+    float *p = nullptr;
+    FDTD_HIP_CHECK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(static_scratch)));
+    if (!p) return (int)hipErrorInvalidSymbol;
+    g_static_scratch_ptr[dev] = p;
+  }
+  *out = g_static_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" int fdtd_hip_two_steps_slab_noalloc(const struct fdtd_geom *g, const float *m, const float *src,
+                                               const float *src_coords, const float *cur, const float *prev,
+                                               float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                                               int src_stride, int coord_stride, int variant, int flags,
+                                               int x_shift, int global_nx, void *stream) {
+  if (!g || global_nx <= 0) return (int)hipErrorInvalidValue;
+  const long need = (long)(g->x_M - g->x_m + 5) * g->nyp * g->nzp;
+  if (g->x_M >= g->x_m && need > (long)FDTD_STATIC_SCRATCH_FLOATS) {
+    fprintf(stderr,
+            "[fdtd-hip] fdtd_hip_two_steps_slab_noalloc: %d planes of %d x %d cells need %ld floats of work space, "
+            "the static buffer holds %ld; use fdtd_hip_two_steps_slab with a caller buffer\n",
+            g->x_M - g->x_m + 1, g->nyp, g->nzp, need, (long)FDTD_STATIC_SCRATCH_FLOATS);
+    return (int)hipErrorInvalidValue;
+  }
+  float *ws = nullptr;
+  const int rc = static_scratch_on_current_device(&ws);
+  if (rc) return rc;
+  return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
+                             coord_stride, variant, flags, x_shift, global_nx, stream, nullptr, nullptr, ws,
+                             (long)FDTD_STATIC_SCRATCH_FLOATS);
 }
 
 extern "C" int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const float *src,

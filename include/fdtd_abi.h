@@ -240,6 +240,24 @@ int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const floa
                            int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
                            int variant, int x_shift, int global_nx, void *stream);
 
+/* fdtd_hip_two_steps_slab without the work-space argument, for callers that cannot allocate
+ * device memory: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  No counterpart in the reference.  The call allocates and frees nothing (no
+ * hipMalloc / hipFree, no allocating library routine); the work space of the two-sweep path is
+ * an array of FDTD_STATIC_SCRATCH_FLOATS floats (16 MiB) inside the library's code object, one
+ * copy per GPU, held until the process ends.  A range of more than that —
+ * (x_M - x_m + 5) * nyp * nzp floats — is refused with hipErrorInvalidValue and a message on
+ * stderr.  Results are those of fdtd_hip_two_steps_slab, bit for bit.  All calls on one GPU share
+ * the array: calls that overlap in time on one GPU (different streams or threads) race.  The
+ * first call on a device looks up the array's address there (hipGetSymbolAddress); make that
+ * call outside graph capture. */
+#define FDTD_STATIC_SCRATCH_FLOATS (4L << 20)
+int fdtd_hip_two_steps_slab_noalloc(const struct fdtd_geom *g, const float *m, const float *src,
+                                    const float *src_coords, const float *cur, const float *prev,
+                                    float *next1, float *next2, int time, int p_src_m, int p_src_M,
+                                    int src_stride, int coord_stride, int variant, int flags,
+                                    int x_shift, int global_nx, void *stream);
+
 /* One step (sweep of openacc.cpp:151-168 + scatter of openacc.cpp:173-203) on three separate
  * level buffers: next = u(time+1) from cur = u(time) and prev = u(time-1). */
 int fdtd_hip_one_step(const struct fdtd_geom *g, const float *m, const float *src,
