@@ -1093,12 +1093,15 @@ __global__ __launch_bounds__(256) void stencil_naive_h16_kernel(StencilArgsH16 h
 }
 
 struct InjectArgsH16 {
-  InjectArgs f;  // u2 member unused
-  __half *u2;
+  InjectArgs f;     // u2 member unused
+  __half *base;     // the [3][nxp][nyp][nzp] array: 4-byte aligned, whatever the parity of a level's size
+  long level_off;   // t2 * nxp*nyp*nzp: first half of the level that is written
 };
 
 // Same scatter as source_inject_kernel; the += on a binary16 element is a compare-and-
-// swap on the aligned 32-bit word that holds it (two corners can share a word).
+// swap on the aligned 32-bit word that holds it (two corners can share a word).  Words are
+// counted from the base of the whole array: a level of an odd number of cells starts on a
+// 2-byte boundary, so words counted from the level would be misaligned.
 __global__ __launch_bounds__(256) void source_inject_h16_kernel(InjectArgsH16 h) {
   const InjectArgs &a = h.f;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1119,8 +1122,9 @@ __global__ __launch_bounds__(256) void source_inject_h16_kernel(InjectArgsH16 h)
                          (posz + FDTD_HALO)];
     const long c = (long)(rx + posx - a.x_shift + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
                    (rz + posz + FDTD_HALO);
-    unsigned int *word = reinterpret_cast<unsigned int *>(h.u2) + (c >> 1);
-    const int shift = (c & 1) ? 16 : 0;
+    const long idx = h.level_off + c;
+    unsigned int *word = reinterpret_cast<unsigned int *>(h.base) + (idx >> 1);
+    const int shift = (idx & 1) ? 16 : 0;
     unsigned int seen = *word, assumed;
     do {
       assumed = seen;
@@ -1184,7 +1188,9 @@ extern "C" int fdtd_hip_source_inject_h16(const struct fdtd_geom *g, const float
   InjectArgs &a = h.f;
   const long vol = (long)g->nxp * g->nyp * g->nzp;
   a.m = m; a.src = src; a.coords = src_coords; a.u2 = nullptr;
-  h.u2 = (__half *)u_h16 + (long)t2 * vol;
+  if ((uintptr_t)u_h16 % 4) return (int)hipErrorInvalidValue;
+  h.base = (__half *)u_h16;
+  h.level_off = (long)t2 * vol;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;

@@ -29,7 +29,7 @@ extern "C" void FDTD_SetRuntimeConfig(int use_tc, int t_fuse, int nfields) {
 }
 
 extern "C" const char *fdtd_hip_version(void) {
-  return "fdtd-hip gfx950 variants=flat,naive,march,tile3d storage=f32,f16";
+  return "fdtd-hip gfx950 variants=flat,naive,march,tile3d,vec,march2 storage=f32,f16";
 }
 
 namespace {

@@ -152,6 +152,11 @@ class SlabPropagator:
             self.step(time)
         self.stepper.finish()
 
+    def reset(self):
+        """Zero wavefield, ready to start again at time 0 (a benchmark repetition, main.cpp:389)."""
+        self.stepper.finish()
+        self.u.zero_()
+
     # planes of level `lvl` sent to / received from the neighbours (contiguous tensor views)
     def send_left(self, lvl):
         return self.u[lvl, HALO:HALO + GHOST]
@@ -296,6 +301,13 @@ class SlabPairPropagator:
         if time <= time_M:
             self.single(time)
         self.stepper.finish()
+
+    def reset(self, time0=0):
+        """Zero wavefield in all four buffers, roles as at `time0` (a benchmark repetition, main.cpp:389)."""
+        self.stepper.finish()
+        for lv in self.levels:
+            lv.zero_()
+        self.cur, self.prev, self.third, self.spare = time0 % 3, (time0 + 2) % 3, (time0 + 1) % 3, 3
 
     def ring(self):
         """The three newest levels in ring order: element i is what slot i of a [3][...] array holds

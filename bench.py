@@ -1,37 +1,45 @@
 #!/usr/bin/env python3
 """Benchmark of the FDTD hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid n] [--variant v]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--grid n] [--variant v]
 
 One "step" is one time step of the propagator (section0 stencil sweep + section1 source
 scatter, reference openacc.cpp:148-205) on fields that are already resident in HBM.
-N = 1 runs BASELINE.json's headline configuration: 512^3 fp32, one Ricker source, the
-LDS-free x-marching kernel (Kernel_CUDA_Optimized's path).  With the defaults W = 5 and
-K = 45 the timed window is steps 5..49 of a 50-step run, i.e. exactly the reference's timer
-window (openacc.cpp:5,148).  N > 1 (launched by torch.distributed.run, one rank per GPU)
-runs the slab-decomposed propagator: every rank owns a 512-plane slab of a (512*N) x 512 x 512
-grid and exchanges 2 ghost planes per side and step with its neighbours over RCCL (weak
-scaling).  Rank 0 prints one JSON line.
+
+N = 1 runs BASELINE.json's headline configuration: 512^3 fp32, one Ricker source, the kernels of
+Kernel_CUDA_Optimized.  With the defaults W = 5 and K = 45 the timed window is steps 5..49 of a
+50-step run, i.e. exactly the reference's timer window (openacc.cpp:5,148).
+
+N > 1 runs the slab-decomposed propagator, one rank per GPU, ghost planes exchanged with the two
+neighbours as RCCL point-to-point messages.  Default: BASELINE.json's multi-GPU configuration, a
+2048^3 grid split into N x-slabs (strong scaling); --weak gives every rank --grid planes instead.
+`python bench.py --gpus N` starts its own N ranks (child processes, started before this process
+touches the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it
+is one of the ranks.
+
+Protocol: the reference driver repeats every configuration 5 times and reports mean and population
+standard deviation (main.cpp:99-111,388).  Here a repetition zeroes the wavefield, does W untimed
+steps and times exactly K steps between barrier + synchronize on both sides (maximum over ranks).
+`value` and `ms_per_step` are the mean over the repetitions; `reps` carries the spread.
+Rank 0 prints one JSON line.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The slab schedule keeps three device queues busy at once (interior chain, boundary chain, RCCL).
-# With HIP's default of 4 hardware queues per process the boundary stream was seen to land on the
-# interior stream's queue, which serialises the two chains; 8 keeps them apart.  Must be in the
-# environment before the HIP runtime initialises, i.e. before torch is imported.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("FDTD_HW_QUEUES", "8")
-
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-ALGO_BYTES_PER_CELL = 16.0     # read u[t0], u[t1], m; write u[t2]; 4 B each
-ALGO_BYTES_PER_CELL_F16 = 10.0  # fp16 storage: u levels 2 B each, m stays 4 B
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
+ALGO_BYTES_PER_UPDATE = 16.0    # fp32: read u[t0], u[t1], m; write u[t2]; 4 B each
+ALGO_BYTES_PER_UPDATE_F16 = 10.0  # fp16 storage: u levels 2 B each, m stays 4 B
+MULTI_GPU_GRID = 2048           # BASELINE.json configs[4]: 2048^3 across the GPUs of a node
 
 
 def parse_args():
@@ -39,14 +47,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=45)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grid", type=int, default=512, help="cells per axis (per-rank slab thickness for N>1)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions (main.cpp:388); mean and population stddev are reported")
+    ap.add_argument("--grid", type=int, default=0,
+                    help="cells per axis; default 512 for one GPU, 2048 (split along x) for several")
     ap.add_argument("--variant", default="auto",
                     choices=["auto", "flat", "naive", "march", "tile3d", "vec", "march2"],
-                    help="auto: two steps per sweep where the shape allows (512-wide z), else the marching kernel")
+                    help="auto: two steps per sweep where the shape allows, else the marching kernel")
     ap.add_argument("--storage", default="f32", choices=["f32", "f16"],
                     help="f16: wavefield levels stored as binary16 in HBM, fp32 arithmetic (config 4; N=1 only)")
     ap.add_argument("--global-x", type=int, default=0,
-                    help="N>1: total planes along x split over the ranks (strong scaling), instead of --grid planes per rank")
+                    help="N>1: total planes along x split over the ranks (default: --grid, i.e. the cube is cut into N slabs)")
+    ap.add_argument("--weak", action="store_true",
+                    help="N>1: every rank owns --grid planes of a (grid*N) x grid x grid domain (weak scaling)")
     ap.add_argument("--self-exchange", action="store_true",
                     help="N=1 rehearsal of the N>1 schedule: the rank is its own two neighbours, RCCL messages "
                          "included (measures what the exchange costs next to the interior sweep; not the headline)")
@@ -55,29 +67,146 @@ def parse_args():
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process starts the ranks and relays rank 0's line.  Nothing here
+# touches torch or HIP: the children are fresh interpreters.
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    failed = None
+    line = None
+    try:
+        out0, _ = None, None
+        pending = set(range(n))
+        while pending and failed is None:
+            for r in sorted(pending):
+                if r == 0:
+                    try:
+                        out0, _ = procs[0].communicate(timeout=0.2)
+                    except subprocess.TimeoutExpired:
+                        continue
+                    rc = procs[0].returncode
+                else:
+                    rc = procs[r].poll()
+                    if rc is None:
+                        continue
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+            time.sleep(0.05)
+        if out0 is not None:
+            for ln in out0.decode(errors="replace").splitlines():
+                if ln.startswith("{"):
+                    line = ln
+                else:
+                    print(ln, file=sys.stderr)
+    finally:
+        for p in procs:            # the ranks this process started, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
+        return 1
+    if line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+def library_source_hash():
+    """Hash of the kernel sources the loaded library was built from (what a traffic measurement is tied to)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "accelerated-3d-acoustic-fdtd-kernel_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(pkg, n, steps):
-    """Time the CPU oracle (test infrastructure; never on the product path) on a bounded sample
-    of the same workload: n^3, `steps` steps of the Ricker run, its own section timers."""
+    """Time the CPU oracle (test infrastructure; never on the product path) on a bounded sample of
+    the same workload: n^3, `steps` steps of the Ricker run, its own section timers, on all the
+    host threads this job may use; and once more on one thread on a smaller grid."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
+    # OMP_NUM_THREADS is the job's CPU share on the GPU box (os.cpu_count() reports the whole machine there)
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    u, m, src, coords = pkg.standard_inputs(n, n, n, steps, 1)
-    prof = ob.run_oracle(m, src, coords, u)
-    timed = steps - pkg.WARMUP_STEPS
-    secs = prof.section0 + prof.section1
-    return {
-        "value": round(n ** 3 * timed / secs / 1e6, 1),
+    lib = ob.oracle()
+    set_threads = getattr(lib, "oracle_set_threads", None)
+
+    def sample(n_, steps_, threads):
+        if set_threads is not None:
+            set_threads(threads)
+        u, m, src, coords = pkg.standard_inputs(n_, n_, n_, steps_, 1)
+        prof = ob.run_oracle(m, src, coords, u)
+        secs = prof.section0 + prof.section1
+        return n_ ** 3 * (steps_ - pkg.WARMUP_STEPS) / secs / 1e6, secs
+
+    rate, secs = sample(n, steps, cores)
+    out = {
+        "value": round(rate, 1),
         "unit": "Mcells/s",
         "cores": cores,
+        "host_cpus_visible": os.cpu_count(),
         "kind": "port",
         "sample": f"{n}^3 fp32 Ricker run, {steps} steps, steps {pkg.WARMUP_STEPS}..{steps - 1} timed "
-                  f"({secs:.2f} s), OpenMP over x,y; bit-identical restatement of openacc.cpp:159-196",
+                  f"({secs:.2f} s), OpenMP over x,y on {cores} threads (the job's CPU share); bit-identical "
+                  f"restatement of openacc.cpp:159-196, standing in for `nvc++ -acc=multicore` (not installed)",
     }
+    if set_threads is not None:
+        n1 = min(n, 256)
+        steps1 = min(steps, 25)
+        rate1, secs1 = sample(n1, steps1, 1)
+        set_threads(cores)
+        out["one_thread"] = {"value": round(rate1, 1), "unit": "Mcells/s", "cores": 1,
+                             "sample": f"{n1}^3, {steps1} steps, {secs1:.2f} s timed"}
+    return out
+
+
+def stats(xs):
+    """Mean and population standard deviation (main.cpp:99-111)."""
+    mean = sum(xs) / len(xs)
+    var = sum((x - mean) ** 2 for x in xs) / len(xs)
+    return mean, var ** 0.5
 
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    slabs = world > 1 or args.self_exchange
+    if slabs:
+        # The slab schedule keeps three device queues busy at once (interior chain, boundary chain,
+        # RCCL).  With HIP's default of 4 hardware queues per process the boundary stream was seen to
+        # land on the interior stream's queue, which serialises the two chains; 8 keeps them apart.
+        # Must be in the environment before the HIP runtime initialises, i.e. before torch is imported.
+        os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("FDTD_HW_QUEUES", "8")
+
     import numpy as np
     import torch
     from __graft_entry__ import load_package
@@ -85,23 +214,26 @@ def main():
     pkg = load_package()
     L = pkg.lib()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 through: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     # one GPU per rank; the modulo only matters when the N>1 path is rehearsed on a 1-GPU box
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
-    n = args.grid
-    K, W = args.steps, args.warmup
+    n = args.grid or (512 if world == 1 else MULTI_GPU_GRID)
+    global_x = 0
+    if world > 1 and not args.weak:
+        global_x = args.global_x or n
+    elif args.global_x:
+        global_x = args.global_x
+    K, W, R = args.steps, args.warmup, max(1, args.reps)
     total_steps = K + W
     variant = pkg.VARIANTS[args.variant]
+    h16 = args.storage == "f16"
+    algo_bytes = ALGO_BYTES_PER_UPDATE_F16 if (h16 and not slabs) else ALGO_BYTES_PER_UPDATE
+    elapsed_reps = []
+    kernel_ms_reps = []
+    exchange = None
 
-    slabs = world > 1 or args.self_exchange
     if slabs:
         import torch.distributed as dist
         if world == 1:
@@ -122,13 +254,14 @@ def main():
             pkg.slab.init_rccl(dev)
         else:
             dist.init_process_group(backend)
+        ranks_seen = dist.get_world_size()
         slab = pkg.slab
         # two steps per exchange (fused sweep, 4-plane ghosts) where the slab's cross-section allows it
         gq = pkg.Geom(n + 8, n + 8, n + 8, 0, n - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
         pairs = args.storage == "f32" and bool(L.fdtd_hip_two_steps_fuses(C.byref(gq), 1, variant))
         maker = slab.standard_pair_benchmark if pairs else slab.SlabPropagator.standard_benchmark
         prop = maker(n_per_rank=n, ny=n, nz=n, nt=total_steps + 1, rank=rank, world=world, device=dev,
-                     variant=variant, global_x=args.global_x, self_exchange=args.self_exchange and world == 1)
+                     variant=variant, global_x=global_x, self_exchange=args.self_exchange and world == 1)
 
         def advance(t_from, t_to):
             t = t_from
@@ -142,33 +275,52 @@ def main():
                 for t in range(t_from, t_to):
                     prop.step(t)
 
-        advance(0, W)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
-        t_start = time.perf_counter()
-        advance(W, total_steps)
-        t_issue = time.perf_counter() - t_start
-        prop.stepper.finish()       # the last step's ghosts have arrived
-        t_fin = time.perf_counter() - t_start
-        dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t_start
-        if os.environ.get("FDTD_BENCH_DEBUG"):
-            print(f"[rank {rank}] issue {t_issue*1e3:.3f} ms, finished {t_fin*1e3:.3f} ms, "
-                  f"after barrier {elapsed*1e3:.3f} ms", file=sys.stderr)
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        for rep in range(R):
+            if rep:
+                prop.reset()
+            advance(0, W)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            if rep == 0:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
+            t_start = time.perf_counter()
+            advance(W, total_steps)
+            t_issue = time.perf_counter() - t_start
+            prop.stepper.finish()       # the last step's ghosts have arrived
+            t_fin = time.perf_counter() - t_start
+            dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t_start
+            if os.environ.get("FDTD_BENCH_DEBUG"):
+                print(f"[rank {rank}] rep {rep}: issue {t_issue*1e3:.3f} ms, finished {t_fin*1e3:.3f} ms, "
+                      f"after barrier {elapsed*1e3:.3f} ms", file=sys.stderr)
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed_reps.append(float(tmax.item()))
         kernel_ms = prop.mean_interior_kernel_ms()
+        kernel_ms_reps = [kernel_ms]
         cells_per_step = float(prop.layout.NX) * n * n
         updates_per_launch = 2 if pairs else 1
         launch_cells = prop.interior_cells() * updates_per_launch
+        # what the exchange costs: per-step time of this run against the kernel time of the interior range
+        # scaled to the whole slab (the time the same cells take without any exchange)
+        nx_loc = prop.layout.nx_loc(rank)
+        own_cells = float(nx_loc) * n * n
+        ms_step = stats(elapsed_reps)[0] / K * 1e3
+        if kernel_ms == kernel_ms and launch_cells > 0:
+            sweep_ms_per_step = kernel_ms / updates_per_launch * own_cells / (launch_cells / updates_per_launch)
+            exchange = {
+                "exposed_ms_per_step": round(max(0.0, ms_step - sweep_ms_per_step), 4),
+                "sweep_only_ms_per_step": round(sweep_ms_per_step, 4),
+                "ghost_bytes_per_side_per_step": (4 if pairs else 2) * (n + 8) * (n + 8) * 4 / (2 if pairs else 1),
+                "transport": "RCCL point-to-point" if backend == "nccl" else "gloo, host staged (rehearsal)",
+            }
         dist.destroy_process_group()
     else:
+        ranks_seen = 1
         u, m, src, coords = pkg.standard_inputs(n, n, n, total_steps, 1)
         u_d = torch.from_numpy(u).to(dev)
         m_d = torch.from_numpy(m).to(dev)
@@ -179,7 +331,6 @@ def main():
         g = pkg.Geom(npad, npad, npad, 0, n - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
         stream = torch.cuda.current_stream()
         sh = C.c_void_p(stream.cuda_stream)
-        h16 = args.storage == "f16"
         if h16:
             u_d = u_d.to(torch.float16)
 
@@ -194,103 +345,156 @@ def main():
 
         # two steps per sweep where the library takes the fused sweep for this box
         fused = (not h16) and K >= 2 and bool(L.fdtd_hip_two_steps_fuses(C.byref(g), 1, variant))
-        updates_per_launch = 1
+        updates_per_launch = 2 if fused else 1
+        use_events = os.environ.get("FDTD_BENCH_EVENTS", "1") != "0"
         if fused:
             # Two steps per sweep: four level buffers rotate (the three ring slots and one more).  All
             # halos are zero and the source sits inside the grid, so no shell has to follow the ring.
-            updates_per_launch = 2
             extra = torch.zeros_like(u_d[0])
             P = [u_d[0], u_d[1], u_d[2], extra]
-            cur, prev, third, spare = 0, 2, 1, 3          # time 0: t0 = 0, t1 = 2, t2 = 1
             margs = (m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr())
-            # The untimed steps take the same kernels as the timed ones (as the operators' time loop does):
-            # one single step if their number is odd, pairs for the rest.  With single steps only, the
-            # process's first launch of the two-step sweep would fall into the timed window (about 1 ms).
-            t = 0
-            if W % 2:
-                assert L.fdtd_hip_one_step(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
-                                           P[third].data_ptr(), t, 0, 0, 1, 3, variant, sh) == 0
-                cur, prev, third = third, cur, prev
-                t += 1
-            while t < W:
-                assert L.fdtd_hip_two_steps_ex(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
-                                               P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, variant, 1,
-                                               None, None, sh) == 0
-                cur, prev, third, spare = spare, third, cur, prev
-                t += 2
             n_pairs = K // 2
             # Every two-step call hands the library two events.  Where the call is a single sweep launch
             # (512-wide rows) they receive the start and stop times of that dispatch itself, which is the
             # kernel duration a profiler reports; otherwise they are recorded on the stream around all the
             # launches of the call (sweep launches, seam pass, scatter).
-            stride = 1
-            ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for i in range(0, n_pairs, stride)}
-            for a, b in ev.values():  # torch creates the HIP event at the first record; the library re-records it
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_pairs)]
+            for a, b in ev:  # torch creates the HIP event at the first record; the library re-records it
                 a.record(stream)
                 b.record(stream)
-            evh = {i: (C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)) for i, (a, b) in ev.items()}
-            torch.cuda.synchronize()
-            t_start = time.perf_counter()
-            t = W
-            for i in range(n_pairs):
-                # The source is inside the grid (flag 1: no halo-corner launches).
-                h = evh.get(i, (None, None)) if os.environ.get("FDTD_BENCH_EVENTS", "1") != "0" else (None, None)
-                rc = L.fdtd_hip_two_steps_ex(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
-                                             P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, variant, 1,
-                                             h[0], h[1], sh)
-                assert rc == 0, rc
-                cur, prev, third, spare = spare, third, cur, prev
-                t += 2
-            if t < total_steps:
-                assert L.fdtd_hip_one_step(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
-                                           P[third].data_ptr(), t, 0, 0, 1, 3, variant, sh) == 0
-                cur, prev, third = third, cur, prev
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t_start
-            if os.environ.get("FDTD_BENCH_EVENTS", "1") != "0":
-                kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev.values()]))
-            else:   # experiment: no events at all, the launch period stands in for the kernel time
-                kernel_ms = elapsed / max(1, n_pairs) * 1e3
-            u_d = torch.stack([P[cur], P[prev], P[third]])
-        else:
-            for t in range(W):
-                assert stencil(t % 3, (t + 2) % 3, (t + 1) % 3) == 0
-                assert inject((t + 1) % 3, t) == 0
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-            torch.cuda.synchronize()
-            t_start = time.perf_counter()
-            for i, t in enumerate(range(W, total_steps)):
-                t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
-                ev[i][0].record(stream)
-                rc = stencil(t0, t1, t2)
-                ev[i][1].record(stream)
-                rc |= inject(t2, t)
-                assert rc == 0, rc
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t_start
-            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            evh = [(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event)) for a, b in ev]
+
+        for rep in range(R):
+            if rep:
+                u_d.zero_()
+                if fused:
+                    extra.zero_()
+            if fused:
+                cur, prev, third, spare = 0, 2, 1, 3          # time 0: t0 = 0, t1 = 2, t2 = 1
+                # The untimed steps take the same kernels as the timed ones (as the operators' time loop does):
+                # one single step if their number is odd, pairs for the rest.  With single steps only, the
+                # process's first launch of the two-step sweep would fall into the timed window (about 1 ms).
+                t = 0
+                if W % 2:
+                    assert L.fdtd_hip_one_step(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
+                                               P[third].data_ptr(), t, 0, 0, 1, 3, variant, sh) == 0
+                    cur, prev, third = third, cur, prev
+                    t += 1
+                while t < W:
+                    assert L.fdtd_hip_two_steps_ex(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
+                                                   P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, variant, 1,
+                                                   None, None, sh) == 0
+                    cur, prev, third, spare = spare, third, cur, prev
+                    t += 2
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+                t = W
+                for i in range(n_pairs):
+                    # The source is inside the grid (flag 1: no halo-corner launches).
+                    hb, he = evh[i] if use_events else (None, None)
+                    rc = L.fdtd_hip_two_steps_ex(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
+                                                 P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, variant, 1,
+                                                 hb, he, sh)
+                    assert rc == 0, rc
+                    cur, prev, third, spare = spare, third, cur, prev
+                    t += 2
+                if t < total_steps:
+                    assert L.fdtd_hip_one_step(C.byref(g), *margs, P[cur].data_ptr(), P[prev].data_ptr(),
+                                               P[third].data_ptr(), t, 0, 0, 1, 3, variant, sh) == 0
+                    cur, prev, third = third, cur, prev
+                torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t_start
+                if use_events:
+                    kernel_ms_reps.append(float(np.mean([a.elapsed_time(b) for a, b in ev])))
+                else:   # experiment: no events at all, the launch period stands in for the kernel time
+                    kernel_ms_reps.append(elapsed / max(1, n_pairs) * 1e3)
+                newest = P[cur]
+            else:
+                for t in range(W):
+                    assert stencil(t % 3, (t + 2) % 3, (t + 1) % 3) == 0
+                    assert inject((t + 1) % 3, t) == 0
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+                for i, t in enumerate(range(W, total_steps)):
+                    t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
+                    ev[i][0].record(stream)
+                    rc = stencil(t0, t1, t2)
+                    ev[i][1].record(stream)
+                    rc |= inject(t2, t)
+                    assert rc == 0, rc
+                torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t_start
+                kernel_ms_reps.append(float(np.mean([a.elapsed_time(b) for a, b in ev])))
+                newest = u_d[total_steps % 3]
+            elapsed_reps.append(elapsed)
+            max_u = float(newest.float().abs().max().item())
+            assert np.isfinite(max_u) and max_u > 0.0, "field is empty or not finite"
+        kernel_ms = float(np.mean(kernel_ms_reps))
         cells_per_step = float(n) ** 3
         launch_cells = cells_per_step * updates_per_launch
-        max_u = float(u_d.float().abs().max().item())
-        assert np.isfinite(max_u) and max_u > 0.0, "field is empty or not finite"
 
     if rank != 0:
         return
 
-    mcells = cells_per_step * K / elapsed / 1e6
-    if not slabs and args.storage == "f16":
-        globals()["ALGO_BYTES_PER_CELL"] = ALGO_BYTES_PER_CELL_F16
-    achieved = ALGO_BYTES_PER_CELL * launch_cells / (kernel_ms * 1e-3) / 1e9  # GB/s, dominant kernel
-    traffic = None
+    mean_s, sd_s = stats(elapsed_reps)
+    mcells = cells_per_step * K / mean_s / 1e6
+    rates = [cells_per_step * K / e / 1e6 for e in elapsed_reps]
+    # roofline.achieved: ALGORITHMIC bytes per launch over the kernel's duration: 16 B per cell update of
+    # the single-step traffic model (10 B with fp16 storage) times the cell updates one launch performs.
+    # The two-step sweep performs two updates per cell and launch while it moves only five level-sized
+    # streams for them (10 B per update, compulsory), so this figure is an equivalent rate, not the
+    # bytes on the HBM pins; those are `traffic` / `physical_GBps` (counters) and `compulsory_GBps`.
+    achieved = algo_bytes * launch_cells / (kernel_ms * 1e-3) / 1e9
+    kernel_bytes_per_update = 10.0 if (updates_per_launch == 2 or (h16 and not slabs)) else 16.0
+    compulsory = kernel_bytes_per_update * launch_cells
+    roof = {
+        "bound": "hbm",
+        "kernel": ("stencil_march2_kernel: two-step sweep, two cell updates and both source scatters per launch"
+                   if updates_per_launch == 2 else "stencil sweep (section0)"),
+        "cell_updates_per_launch": launch_cells,
+        "achieved": round(achieved, 1),
+        "achieved_basis": f"{algo_bytes:g} B per cell update (algorithmic, single-step model) x cell updates per launch / kernel time",
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "avg_kernel_ms": round(kernel_ms, 4),
+        "compulsory_bytes_per_launch": compulsory,
+        "compulsory_GBps": round(compulsory / (kernel_ms * 1e-3) / 1e9, 1),
+    }
+    # HBM bytes per launch from the PMC counters: measured in separate profiler passes
+    # (tools/profile_bench.sh) and only valid for the kernel sources and workload they were taken on.
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and not slabs and n % 512 == 0 and args.storage == "f32" and args.variant == "auto":
+    if os.path.exists(tpath) and not slabs:
         try:
             tj = json.load(open(tpath))
             want = "stencil_march2" if updates_per_launch == 2 else "stencil_march_lds"
-            traffic = tj.get("hbm_bytes_per_launch") if tj.get("kernel", "stencil_march_lds") == want else None
+            same = (tj.get("kernel") == want and tj.get("library_source_hash") == library_source_hash()
+                    and tj.get("grid") == n and tj.get("storage", "f32") == args.storage
+                    and tj.get("variant", "auto") == args.variant)
+            if same:
+                roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = {"file": "profiles/traffic_latest.json", "kernel": tj.get("kernel"),
+                                          "library_source_hash": tj.get("library_source_hash"),
+                                          "method": tj.get("note")}
+                roof["physical_GBps"] = round(roof["traffic"] / (kernel_ms * 1e-3) / 1e9, 1)
+                roof["physical_frac"] = round(roof["physical_GBps"] / HBM_PEAK_GBS, 4)
+            else:
+                roof["traffic_source"] = "profiles/traffic_latest.json was measured on other kernel sources or another workload"
         except Exception:
-            traffic = None
+            pass
+    if not slabs:
+        wl = (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
+              f"{total_steps} steps ({W} untimed)")
+    else:
+        NX = int(cells_per_step / n / n)
+        wl = (f"{NX}x{n}x{n} fp32 as {world} x-slabs, "
+              + ("two steps per sweep and exchange (4 ghost planes of u(t+2) per side)" if updates_per_launch == 2
+                 else "2-plane ghost exchange per step")
+              + (" over RCCL" if os.environ.get("FDTD_BENCH_BACKEND", "nccl") == "nccl"
+                 else " over gloo (host-staged rehearsal)")
+              + f", {total_steps} steps ({W} untimed)")
     out = {
         "metric": "Mcells/s",
         "value": round(mcells, 1),
@@ -298,38 +502,32 @@ def main():
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": round(elapsed / K * 1e3, 4),
+        "ms_per_step": round(mean_s / K * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if (world > 1 and args.global_x) else "weak",
+        "scaling": "strong" if (world > 1 and global_x) else "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.storage == "f32" else "f32 arithmetic, f16 storage",
         "data": "synthetic",
-        "achieved_hbm_GBps_whole_step": round(mcells * ALGO_BYTES_PER_CELL / 1e3, 1),
+        "effective_GBps_at_algorithmic_bytes": round(mcells * algo_bytes / 1e3, 1),
+        "reps": {
+            "n": R,
+            "protocol": "each repetition: zeroed field, warm-up steps untimed, then the timed steps (main.cpp:388-399)",
+            "ms_per_step_mean": round(mean_s / K * 1e3, 4),
+            "ms_per_step_stddev": round(sd_s / K * 1e3, 4),
+            "Mcells_per_s": [round(r, 1) for r in rates],
+            "Mcells_per_s_stddev": round(stats(rates)[1], 1),
+        },
         "config": {
-            "workload": (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
-                         f"{total_steps} steps ({W} untimed)" if not slabs else
-                         f"{int(cells_per_step / n / n)}x{n}x{n} fp32 as {world} x-slabs, "
-                         + ("two steps per sweep and exchange (4 ghost planes of u(t+2) per side)" if updates_per_launch == 2
-                            else "2-plane ghost exchange per step")
-                         + (" over RCCL" if os.environ.get("FDTD_BENCH_BACKEND", "nccl") == "nccl"
-                            else " over gloo (host-staged rehearsal)")
-                         + f", {total_steps} steps ({W} untimed)"),
+            "workload": wl,
             "variant": args.variant,
-            "bytes_per_cell_update": ALGO_BYTES_PER_CELL,
+            "algorithmic_bytes_per_cell_update": algo_bytes,
+            "kernel_bytes_per_cell_update": kernel_bytes_per_update,
+            "ranks": ranks_seen,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": ("stencil_march2_kernel: two-step sweep, two cell updates and both source scatters per launch"
-                       if updates_per_launch == 2 else "stencil sweep (section0)"),
-            "cell_updates_per_launch": launch_cells,
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "avg_kernel_ms": round(kernel_ms, 4),
-        },
+        "roofline": roof,
     }
+    if exchange is not None:
+        out["exchange"] = exchange
     if slabs and world == 1:
         out["config"]["workload"] += " [one rank, own neighbour on both sides: schedule rehearsal]"
     if world == 1 and not slabs and not args.no_cpu_baseline:

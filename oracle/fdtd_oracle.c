@@ -39,6 +39,20 @@
 
 #include "../include/fdtd_abi.h"
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Number of OpenMP threads of the following sweeps (the benchmark's CPU baseline times the
+ * oracle on all threads of the job and on one). */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 static double now_s(void) {
   struct timeval tv;
   gettimeofday(&tv, NULL);

@@ -1,0 +1,49 @@
+"""bench.py as the driver invokes it: `python bench.py --gpus N` starts its own ranks, prints one JSON
+line on stdout and exits 0; a WORLD_SIZE that contradicts --gpus is an error before anything is loaded."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """Two ranks on the one GPU of the box, ghosts staged through the host (gloo): the N > 1 code path of
+    bench.py from the plain command line, strong scaling of a 128 x 512 x 512 grid."""
+    env = dict(os.environ, FDTD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--grid", "512", "--global-x", "128", "--steps", "6",
+                        "--warmup", "2", "--reps", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2
+    assert out["scaling"] == "strong" and out["steps"] == 6 and out["reps"]["n"] == 2
+    assert out["value"] > 0 and "128x512x512" in out["config"]["workload"]
+    assert "exchange" in out
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+    """The N = 1 line at a reduced size: repetitions, roofline and CPU baseline objects are present."""
+    r = subprocess.run([sys.executable, BENCH, "--grid", "256", "--steps", "10", "--warmup", "5", "--reps", "3",
+                        "--cpu-steps", "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["reps"]["n"] == 3 and len(out["reps"]["Mcells_per_s"]) == 3
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"]
+    assert out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["one_thread"]["cores"] == 1

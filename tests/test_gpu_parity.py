@@ -484,7 +484,9 @@ def test_fp16_storage_random_field(pkg, hiplib, monkeypatch):
     monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0")
     c = cases.build("tile_edges_100", pkg)          # 12 x 100 x 260: z extent 260 is not a multiple of 8
     c2 = cases.build("full_tiles_256", pkg)         # 11 x 32 x 256
-    for case in (c, c2):
+    c3 = cases.build("odd_sizes", pkg)              # 17 x 33 x 65: a level has an odd number of cells, so the
+                                                    # second level starts on a 2-byte boundary (scatter words)
+    for case in (c, c2, c3):
         u = case["u"].astype(np.float16).astype(np.float32)
         nt = case["src"].shape[0]
         shape = tuple(d - 8 for d in u.shape[1:])
