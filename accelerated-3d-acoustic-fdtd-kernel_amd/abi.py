@@ -82,10 +82,17 @@ def lib():
             f"{path} is missing: build it with `make -C {_HERE}` (hipcc --offload-arch=gfx950); "
             "this engine has no CPU fallback")
     L = C.CDLL(path)
-    for name in ("Kernel_OpenACC", "Kernel_CUDA", "Kernel_CUDA_Optimized", "Kernel_HIP_FP16Storage"):
+    for name in ("Kernel_OpenACC", "Kernel_CUDA", "Kernel_CUDA_Optimized", "Kernel_HIP_FP16Storage",
+                 "Kernel_HIP_MultiGPU"):
         fn = getattr(L, name)
         fn.argtypes = OPERATOR_ARGTYPES
         fn.restype = C.c_int
+    L.fdtd_hip_multigpu_last_slab_count.argtypes = []
+    L.fdtd_hip_multigpu_last_slab_count.restype = C.c_int
+    L.fdtd_hip_release_device_copies.argtypes = []
+    L.fdtd_hip_release_device_copies.restype = None
+    L.fdtd_hip_last_call_phases.argtypes = [C.POINTER(C.c_double * 4)]
+    L.fdtd_hip_last_call_phases.restype = None
     L.fdtd_hip_stencil_step.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p]
     L.fdtd_hip_stencil_step.restype = C.c_int

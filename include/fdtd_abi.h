@@ -95,6 +95,33 @@ int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS);
  * cuda_optimized.cu:59-61,261-279,482-499).  Host buffers stay fp32. */
 int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS);
 
+/* The same operator on several GPUs of one node, driven by the calling thread: the x range is cut
+ * into one slab per device, every pair of time steps ends with a push of 4 ghost planes to each
+ * neighbour (hipMemcpyPeerAsync: copy engines over xGMI, no compute units), overlapped with the
+ * interior sweep on a second stream.  No counterpart in the reference, which is single-device; the
+ * result is bit for bit that of Kernel_CUDA_Optimized.  Devices: deviceid = -1 takes all visible
+ * ones (FDTD_NGPUS limits their number; with deviceid >= 0 that many starting there, default one);
+ * FDTD_MULTIGPU_DEVICES="0,1,2" names them (a device named twice carries two slabs).  A call whose x
+ * range is not the whole extent of the arrays, or with fewer than 16 planes, runs on the first
+ * device alone.  timers->section0 receives the wall time of steps time_m+5 .. time_M over all
+ * devices (host clock between device-wide synchronisations), section1 nothing: the scatter is part
+ * of the sweep. */
+int Kernel_HIP_MultiGPU(FDTD_OPERATOR_ARGS);
+/* Number of slabs the last Kernel_HIP_MultiGPU call was cut into (1: handed to one device). */
+int fdtd_hip_multigpu_last_slab_count(void);
+
+/* Device copies across calls.  An operator call with devicerm = 0 leaves its device arrays on the
+ * device, as openacc.cpp:208-212 does (delete ... if(devicerm)); a later call with the same host
+ * arrays (same u and m pointers, same shapes, same device) computes on them without uploading u or
+ * m again (src and src_coords are small and always refreshed); u is copied back to the host at
+ * the end of every call either way.  If the host changes u between two such calls, set
+ * FDTD_RESIDENT_REUPLOAD_U=1.  devicerm != 0 frees the copies at the end of the call;
+ * fdtd_hip_release_device_copies frees whatever earlier calls left behind. */
+void fdtd_hip_release_device_copies(void);
+/* Host-side phase times of the last operator call, in milliseconds: allocation, copies to the
+ * device, time loop, copy to the host. */
+void fdtd_hip_last_call_phases(double out_ms[4]);
+
 /* Optional hook the reference driver looks up as a weak symbol and calls once per
  * benchmark sweep (main.cpp:84,266-276).  The call records the values and returns.
  * t_fuse >= 2 makes Kernel_CUDA_Optimized take the two-steps-per-sweep kernel whatever
