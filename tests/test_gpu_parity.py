@@ -494,3 +494,51 @@ def test_fp16_storage_random_field(pkg, hiplib, monkeypatch):
         rc, _ = pkg.run_operator(hiplib.Kernel_HIP_FP16Storage, case["m"], case["src"], case["coords"], u, **case["kw"])
         assert rc == 0
         assert ob.bits_equal(u, ue)
+
+
+def test_fp16_storage_512_cubed(pkg, hiplib):
+    """Config 4 at its full size: 512^3, fp16 storage, the Ricker benchmark inputs, a dozen steps, bit for
+    bit against the oracle stepped with a round-to-binary16 after every store (the pinned fp32 oracle plus
+    numpy's IEEE rounding; there is no reference kernel that time-steps fp16 state)."""
+    n, nt = (512, 512, 512), 12
+    u, m, src, coords = pkg.standard_inputs(*n, nt, 1)
+    ue = fp16_emulation(ob, u, m, src, coords, n, nt, (0.1, 0.1, 0.1))
+    rc, prof = pkg.run_operator(hiplib.Kernel_HIP_FP16Storage, m, src, coords, u)
+    assert rc == 0 and prof.section0 > 0
+    assert float(np.abs(u).max()) > 0
+    assert ob.bits_equal(u, ue)
+
+
+@pytest.mark.parametrize("shape,nsrc,what", [((32, 512, 1024), 3, "two z-tiles of 512 cells: seam pass"),
+                                             ((36, 500, 1000), 2, "masked tiles in y and z"),
+                                             ((40, 640, 640), 12, "more than 8 sources: scatter and repair passes"),
+                                             ((48, 768, 768), 2, "three z-tiles of 256 cells")])
+def test_large_fused_shapes_against_oracle(pkg, hiplib, shape, nsrc, what):
+    """The two-step sweep on cross-sections of the size the benchmarks use (16 M cells and more), compared with
+    the CPU oracle directly rather than with another HIP kernel: random fields with different halos per level,
+    varying m, anisotropic spacing, sources on a z-cut, in the outermost cell and (12 sources) overlapping."""
+    nx, ny, nz = shape
+    nt = 9
+    rng = np.random.default_rng(2024)
+    pshape = (nx + 8, ny + 8, nz + 8)
+    u = np.zeros((3,) + pshape, dtype=np.float32)
+    u[0] = rng.uniform(-1, 1, size=pshape).astype(np.float32)
+    u[1] = u[0] + rng.uniform(-0.01, 0.01, size=pshape).astype(np.float32)
+    u[2] = rng.uniform(-1, 1, size=pshape).astype(np.float32)
+    m = rng.uniform(1, 3, size=pshape).astype(np.float32)
+    h = (0.9, 1.0, 1.1)
+    src = rng.uniform(-50, 50, size=(nt, nsrc)).astype(np.float32)
+    ext = np.array([nx - 1, ny - 1, nz - 1]) * np.array(h)
+    coords = (rng.uniform(0.05, 0.95, size=(nsrc, 3)) * ext).astype(np.float32)
+    coords[0] = ((nx - 1) * h[0] + 0.3 * h[0], 0.0, (nz - 1) * h[2])        # outermost cell: halo-layer corners
+    coords[1, 2] = np.float32(511.5 * h[2])                                    # corners at z = 511 | 512
+    if nsrc > 8:
+        coords[3] = coords[2] + np.array([1.2 * h[0], 0.0, 0.6 * h[2]], dtype=np.float32)   # overlapping stars
+        coords[5] = coords[4]                                                                # coincident corners
+    u_ref = u.copy()
+    ob.run_oracle(m, src, coords, u_ref, h=h)
+    before = hiplib.fdtd_hip_fused_launch_count()
+    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, h=h)
+    assert rc == 0
+    assert hiplib.fdtd_hip_fused_launch_count() > before, what
+    assert ob.bits_equal(u, u_ref), what
