@@ -126,13 +126,16 @@ __device__ __forceinline__ f32x2 update_pair(const Coef2 &k, f32x2 uc, f32x2 xm2
   return f32x2{num.x / mc.x, num.y / mc.y};
 }
 // edge_r: this lane's right neighbours are eR even though it is not lane 63 (the last lane of a row
-// that ends inside the wave).  offer: what this lane shows the lane before it as cells 0 and 1
-// (its own c.x, c.y, except in the lane behind a row that ends on lane 0 of a wave).
+// that ends inside the wave, or of a row part that is a half-wave).  edge_l: its left neighbours are eL
+// even though it is not lane 0 (the first lane of the second half-wave).  offer: what this lane shows
+// the lane before it as cells 0 and 1 (its own c.x, c.y, except in the lane behind a row that ends on
+// the first lane of a row part).
 __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, f32x4 xm1, f32x4 xp1, f32x4 xp2,
                                             f32x4 ym2, f32x4 ym1, f32x4 yp1, f32x4 yp2, f32x2 eL, f32x2 eR, f32x4 up,
-                                            f32x4 mc, bool edge_r, f32x2 offer) {
-  const f32x2 l = f32x2{dpp_prev(eL.x, c.z), dpp_prev(eL.y, c.w)};   // cells z-2, z-1 of cell 0
+                                            f32x4 mc, bool edge_r, f32x2 offer, bool edge_l = false) {
+  f32x2 l = f32x2{dpp_prev(eL.x, c.z), dpp_prev(eL.y, c.w)};         // cells z-2, z-1 of cell 0
   f32x2 r = f32x2{dpp_next(eR.x, offer.x), dpp_next(eR.y, offer.y)}; // cells z+1, z+2 of cell 3
+  l = edge_l ? eL : l;
   r = edge_r ? eR : r;
   const f32x2 cl = lo2(c), ch = hi2(c);
   // cells 0,1: z-2: (l.x, l.y)  z+2: (c.z, c.w)   z-1: (l.y, c.x)  z+1: (c.y, c.z)
@@ -154,18 +157,29 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // the row and rows beyond y_M compute on clamped addresses and store nothing; the last lane inside
 // the row takes its right neighbours from the edge loads (as lane 63 of a full row does), and a
 // row beyond y_M contributes what the C level holds there in memory, like any other halo row.
-template <bool NT, int ZH, bool MASK>
+// LPR = 32 (with ZH = 1): rows of 128 cells; every half-wave is a tile of its own, so the workgroup carries
+// four independent 8-row tiles stacked in y (32 rows per workgroup).  Rows, and with them every row
+// offset and every "row outside the box" condition, then differ between the two halves of a wave: row
+// offsets move from the scalar to the per-lane part of the addresses, and the lanes 31 | 32 take their
+// z-neighbours from the edge loads like the lanes 0 and 63 do.  For cross-sections whose rows fill
+// multiples of 128 cells much better than multiples of 256 or 512 (384, 640).
+template <bool NT, int ZH, bool MASK, int LPR = 64>
 __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt, int wg_base) {
+  static_assert(LPR == 64 || (LPR == 32 && ZH == 1), "half-wave tiles exist for rows of 128 cells only");
+  constexpr int TILE_CELLS = ZH == 2 ? M2_ZCELLS : LPR * 4;   // z extent of a tile
+  constexpr int TILE_F4 = TILE_CELLS / 4;                       // float4s per tile row
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
   const int lane = threadIdx.x & 63;
+  const int zl = LPR == 64 ? lane : (lane & 31);     // position inside the row part
+  const int half = LPR == 64 ? 0 : (lane >> 5);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = wave & 1, q = wave >> 1;
   const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
   // z-tile fastest: the tiles on either side of a z-cut read each other's edge cells and should share an L2
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
-  const int zb = a.z_m + zt * (ZH == 2 ? M2_ZCELLS : M2_ZCELLS / 2);   // first cell of this z-tile
-  const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (2 * yt + h) * M2_ROWS);
+  const int zb = a.z_m + zt * TILE_CELLS;   // first cell of this z-tile
+  const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (LPR == 64 ? (2 * yt + h) : (4 * yt + 2 * h + half)) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
   const Coef2 k = a.k;
@@ -176,36 +190,57 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const bool seg2_outside = yrow[2] < a.y_m || yrow[2] > a.y_M;
   // MASK: an output row may lie beyond y_M as well (never below y_m: tiles start at y_m)
   const bool out0 = MASK && yrow[0] > a.y_M, out1 = MASK && yrow[1] > a.y_M;
+  // Half-wave tiles: these conditions differ between the two halves of a wave.  No memory instruction
+  // may sit under a divergent branch (the counted waits would no longer be exact), so the loads they
+  // guard are issued by the whole wave as soon as either half needs them, and selected per lane.
+  const bool ld_seg2 = LPR == 64 ? seg2_outside : (__ballot(seg2_outside) != 0);
+  const bool ld_out0 = LPR == 64 ? out0 : (MASK && __ballot(out0) != 0);
+  const bool ld_out1 = LPR == 64 ? out1 : (MASK && __ballot(out1) != 0);
   const int yhalo = q < 2 ? yb - 4 + q : yb + 8 + q;   // B row outside the 12-row stack
   const int hslot = q < 2 ? q : 12 + q;
   const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
-  const int lz = ZH == 2 ? lc : lane;                   // float4 index inside the row of cells
-  const bool seam_lane = (lz == 0 && zt > 0) || (lz == 64 * ZH - 1 && zt < nzt - 1);   // next to a z-cut
+  const int lz = ZH == 2 ? lc : zl;                     // float4 index inside the row of cells
+  const bool seam_lane = (lz == 0 && zt > 0) || (lz == TILE_F4 - 1 && zt < nzt - 1);   // next to a z-cut
   // MASK: float4s of this z-tile that are inside the row; lanes from nvalid on work on the address
   // of float4 `nvalid` (the four halo cells behind the row) and store nothing
-  const int nvalid = MASK ? min(64 * ZH, (a.z_M + 1 - zb) >> 2) : 64 * ZH;
+  const int nvalid = MASK ? min(TILE_F4, (a.z_M + 1 - zb) >> 2) : TILE_F4;
   const bool lane_valid = !MASK || lz < nvalid;
   // The last lane inside the row takes its right neighbours from the edge loads.  When that lane
   // is lane 0 of its wave the edge loads are taken by its left neighbours; lane 1, which sits on
   // the halo cells behind the row, then shows it those: its B registers hold them anyway, and for
   // the C level it loads them from memory in place of its edge cells (offers_halo).
-  const bool last_valid = MASK && lz == nvalid - 1 && lane != 0;
-  const bool offers_halo = MASK && lz == nvalid && lane == 1;
-  const bool edge_hi = (lane == 63 && lane_valid) || last_valid;
+  const bool last_valid = MASK && lz == nvalid - 1 && zl != 0;
+  const bool offers_halo = MASK && lz == nvalid && zl == 1;
+  const bool edge_hi = (zl == LPR - 1 && lane_valid) || last_valid;
+  // half-wave tiles: explicit selects where a lane shift would cross into the other tile
+  const bool sel_l = LPR == 32 && zl == 0;
+  const bool sel_r = last_valid || (LPR == 32 && zl == LPR - 1);
   // the row ends in this wave or before it: nothing to the right of the wave comes from LDS
   const bool row_ends_here = MASK && nvalid <= (ZH == 2 ? (h + 1) * 64 : 64);
   // Addresses: descriptor base + scalar offset (plane + row, wave-uniform) + one lane offset along z.
   // vz: the lane's 4 cells; vze: the 2 cells before them, or behind them in the last lane; vzc: the
   // same for the C array, where only the two cells before lane 0 / behind the last lane are ever
   // used, so the lanes in between repeat lane 0's address instead of touching the whole row.
-  const unsigned vz0 = (unsigned)(zb + (lz - lane) * 4 + FDTD_HALO) * 4u;   // lane 0 of this wave
+  const unsigned vz0 = (unsigned)(zb + (lz - zl) * 4 + FDTD_HALO) * 4u;   // first lane of this row part
   const unsigned vz = (unsigned)(zb + (MASK ? min(lz, nvalid) : lz) * 4 + FDTD_HALO) * 4u;
   const unsigned vze = edge_hi ? vz + 16u : vz - 8u;
   const unsigned vzc = edge_hi ? vz + 16u : (offers_halo ? vz : vz0 - 8u);
-  int rowoff[3];   // byte offset of the segment's row inside a plane (MASK: rows clamped to the array)
+  // byte offset of a segment's row inside a plane (MASK: rows clamped to the array): wave-uniform and
+  // part of the scalar offset when a wave works on one tile; per lane, folded into the lane offsets,
+  // when its halves work on different tiles (LPR = 32)
+  int rowoff[3];
+  unsigned vzs[3], vzes[3], vzcs[3];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) rowoff[s] = ((MASK ? min(yrow[s], a.y_M + 4) : yrow[s]) + FDTD_HALO) * a.sy * 4;
-  const int rowoff_h = ((MASK ? min(yhalo, a.y_M + 4) : yhalo) + FDTD_HALO) * a.sy * 4;
+  for (int s = 0; s < 3; ++s) {
+    const int ro = ((MASK ? min(yrow[s], a.y_M + 4) : yrow[s]) + FDTD_HALO) * a.sy * 4;
+    rowoff[s] = LPR == 64 ? ro : 0;
+    vzs[s] = LPR == 64 ? vz : vz + (unsigned)ro;
+    vzes[s] = LPR == 64 ? vze : vze + (unsigned)ro;
+    vzcs[s] = LPR == 64 ? vzc : vzc + (unsigned)ro;
+  }
+  const int ro_h = ((MASK ? min(yhalo, a.y_M + 4) : yhalo) + FDTD_HALO) * a.sy * 4;
+  const int rowoff_h = LPR == 64 ? ro_h : 0;
+  const unsigned vzh = LPR == 64 ? vz : vz + (unsigned)ro_h;
   const int sxb = (int)(a.sx * 4);   // bytes per plane
 
   // descriptors are based at the lowest plane this workgroup touches, so that plane offsets stay
@@ -279,11 +314,19 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, (sp + (i - 2) * sxb) + rowoff[s], vz);
-    if (MASK && ((s == 0 && out0) || (s == 1 && out1))) av[s] = LD4(rC, sp + rowoff[s], vz);   // the C row itself
-    else av[s] = s == 0 ? LD4S(rA, sp + rowoff[s], vz) : LD4(rA, sp + rowoff[s], vz);
-    mv[s] = s == 0 ? LD4S(rM, sp + rowoff[s], vz) : LD4(rM, sp + rowoff[s], vz);
-    be[s] = LD2(rB, sp + rowoff[s], vze);
+    for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, (sp + (i - 2) * sxb) + rowoff[s], vzs[s]);
+    if (LPR == 64) {
+      if (MASK && ((s == 0 && out0) || (s == 1 && out1))) av[s] = LD4(rC, sp + rowoff[s], vzs[s]);   // the C row itself
+      else av[s] = s == 0 ? LD4S(rA, sp + rowoff[s], vzs[s]) : LD4(rA, sp + rowoff[s], vzs[s]);
+    } else {
+      av[s] = s == 0 ? LD4S(rA, sp + rowoff[s], vzs[s]) : LD4(rA, sp + rowoff[s], vzs[s]);
+      if (MASK && ((s == 0 && ld_out0) || (s == 1 && ld_out1))) {
+        const f32x4 crow = LD4(rC, sp + rowoff[s], vzs[s]);
+        av[s] = (s == 0 ? out0 : out1) ? crow : av[s];
+      }
+    }
+    mv[s] = s == 0 ? LD4S(rM, sp + rowoff[s], vzs[s]) : LD4(rM, sp + rowoff[s], vzs[s]);
+    be[s] = LD2(rB, sp + rowoff[s], vzes[s]);
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -292,14 +335,14 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     mh[0][s] = mh[1][s] = f32x4{1, 1, 1, 1};
     ce[s] = f32x2{0, 0};
   }
-  bh = LD4(rB, (sp + sxb) + rowoff_h, vz);
-  bh2 = LD4(rB, (sp + 2 * sxb) + rowoff_h, vz);
-  ch = seg2_outside ? LD4(rC, sp + rowoff[2], vz) : f32x4{0, 0, 0, 0};
+  bh = LD4(rB, (sp + sxb) + rowoff_h, vzh);
+  bh2 = LD4(rB, (sp + 2 * sxb) + rowoff_h, vzh);
+  ch = ld_seg2 ? LD4(rC, sp + rowoff[2], vzs[2]) : f32x4{0, 0, 0, 0};
   {  // B(p0): own rows and the outside row
     const int buf = p0 & 1;
 #pragma unroll
     for (int s = 0; s < 3; ++s) Bbuf[buf][cslot[s] + 2][lc] = bc[2][s];
-    Bbuf[buf][hslot][lc] = LD4(rB, sp + rowoff_h, vz);
+    Bbuf[buf][hslot][lc] = LD4(rB, sp + rowoff_h, vzh);
   }
   __syncthreads();
   int ring_w = ((p0 % 3) + 3) % 3;        // ring slot written this iteration (plane p)
@@ -334,21 +377,21 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
         const f32x4 ym2 = Bbuf[buf][r][lc], ym1 = Bbuf[buf][r + 1][lc];
         const f32x4 yp1 = Bbuf[buf][r + 3][lc], yp2 = Bbuf[buf][r + 4][lc];
         cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
-                          mv[s], last_valid, lo2(PB(2)[s]));
+                          mv[s], sel_r, lo2(PB(2)[s]), sel_l);
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
         if constexpr (MASK && s < 2) cnew = (s == 0 ? out0 : out1) ? av[s] : cnew;
         if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
       } else {   // halo plane of the domain: the intermediate level keeps what memory holds there
-        cnew = LD4(rC, sp + rowoff[s], vz);
+        cnew = LD4(rC, sp + rowoff[s], vzs[s]);
       }
       const bool row_out = s == 0 ? out0 : (s == 1 ? out1 : false);
       if constexpr (s < 2) {
         if (store_c && !row_out) {
-          if (lane_valid) st4<NT>(rC, sp + rowoff[s], vz, cnew);
+          if (lane_valid) st4<NT>(rC, sp + rowoff[s], vzs[s], cnew);
         }
         // planes before and behind the chunk: their C exists only here, and seam_kernel needs it
         // next to the z-cuts (a chunk beside this one, or the owner of the plane, stores the same bits)
-        else if (!STEADY && !store_c && !row_out && plane_inside && seam_lane) st4<false>(rC, sp + rowoff[s], vz, cnew);
+        else if (!STEADY && !store_c && !row_out && plane_inside && seam_lane) st4<false>(rC, sp + rowoff[s], vzs[s], cnew);
       }
       Cring[ring_w][r][lc] = cnew;
       // ---- D(p-2) ----
@@ -363,10 +406,10 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
             else if (!row_ends_here) eR = f32x2{nb.x, nb.y};
           }
           f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
-                               PB(0)[s], mh[0][s], last_valid, offers_halo ? ce[s] : lo2(PC(2)[s]));
+                               PB(0)[s], mh[0][s], sel_r, offers_halo ? ce[s] : lo2(PC(2)[s]), sel_l);
           if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
           if (!row_out) {
-            if (lane_valid) st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vz, o);
+            if (lane_valid) st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vzs[s], o);
           }
         }
         if (STEADY) {
@@ -385,22 +428,30 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     auto reload = [&](auto seg) __attribute__((always_inline)) {
       constexpr int s = decltype(seg)::value;
       const int r = cslot[s];
-      if constexpr (s < 2) ce[s] = LD2(rC, (sq - 2 * sxb) + rowoff[s], vzc);   // C array, plane (p+1)-2
+      if constexpr (s < 2) ce[s] = LD2(rC, (sq - 2 * sxb) + rowoff[s], vzcs[s]);   // C array, plane (p+1)-2
       if (STEADY) {
         Bbuf[buf ^ 1][r + 2][lc] = PB(3)[s];           // B(p+1), centre plane of the next iteration
-        PB(0)[s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);     // B(p+3) replaces B(p-2)
+        PB(0)[s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vzs[s]);     // B(p+3) replaces B(p-2)
       } else {
         bc[0][s] = bc[1][s];
         bc[1][s] = bc[2][s];
         bc[2][s] = bc[3][s];
         bc[3][s] = bc[4][s];
         Bbuf[buf ^ 1][r + 2][lc] = bc[2][s];
-        bc[4][s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vz);
+        bc[4][s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vzs[s]);
       }
-      if (MASK && ((s == 0 && out0) || (s == 1 && out1))) av[s] = LD4(rC, sq + rowoff[s], vz);
-      else av[s] = s == 0 ? LD4S(rA, sq + rowoff[s], vz) : LD4(rA, sq + rowoff[s], vz);
-      mv[s] = s == 0 ? LD4S(rM, sq + rowoff[s], vz) : LD4(rM, sq + rowoff[s], vz);
-      be[s] = LD2(rB, sq + rowoff[s], vze);
+      if (LPR == 64) {
+        if (MASK && ((s == 0 && out0) || (s == 1 && out1))) av[s] = LD4(rC, sq + rowoff[s], vzs[s]);
+        else av[s] = s == 0 ? LD4S(rA, sq + rowoff[s], vzs[s]) : LD4(rA, sq + rowoff[s], vzs[s]);
+      } else {
+        av[s] = s == 0 ? LD4S(rA, sq + rowoff[s], vzs[s]) : LD4(rA, sq + rowoff[s], vzs[s]);
+        if (MASK && ((s == 0 && ld_out0) || (s == 1 && ld_out1))) {
+          const f32x4 crow = LD4(rC, sq + rowoff[s], vzs[s]);
+          av[s] = (s == 0 ? out0 : out1) ? crow : av[s];
+        }
+      }
+      mv[s] = s == 0 ? LD4S(rM, sq + rowoff[s], vzs[s]) : LD4(rM, sq + rowoff[s], vzs[s]);
+      be[s] = LD2(rB, sq + rowoff[s], vzes[s]);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -416,8 +467,8 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
     reload(S0{});
     Bbuf[buf ^ 1][hslot][lc] = bh;
     bh = bh2;
-    bh2 = LD4(rB, (sq + 2 * sxb) + rowoff_h, vz);
-    if (seg2_outside) ch = LD4(rC, sq + rowoff[2], vz);
+    bh2 = LD4(rB, (sq + 2 * sxb) + rowoff_h, vzh);
+    if (ld_seg2) ch = LD4(rC, sq + rowoff[2], vzs[2]);
     __syncthreads();
     ring_w = ring_w == 2 ? 0 : ring_w + 1;
     ring_r = ring_r == 2 ? 0 : ring_r + 1;
@@ -588,24 +639,41 @@ int env_int2(const char *name, int fallback) {
 // its lanes and rows on padding is taken; a cross-section that does not fill its tiles exactly
 // runs the kernel's MASK variant.
 struct M2Tiling {
-  bool wide, mask;
-  int zstep, tile_rows, nyt, nzt;
+  int zstep;     // cells per z-tile: 512 (one 8-row tile per workgroup), 256 (two), 128 (four)
+  bool mask;
+  int tile_rows, nyt, nzt;
   double fill;   // cells of the cross-section / cells the tiles span
 };
 static M2Tiling m2_tiling(int ey, int ez) {
-  auto make = [&](bool wide) {
+  auto make = [&](int zstep) {
     M2Tiling t;
-    t.wide = wide;
-    t.zstep = wide ? M2_ZCELLS : M2_ZCELLS / 2;
-    t.tile_rows = wide ? M2_ROWS : 2 * M2_ROWS;
+    t.zstep = zstep;
+    t.tile_rows = M2_ROWS * (M2_ZCELLS / zstep);
     t.nyt = (ey + t.tile_rows - 1) / t.tile_rows;
     t.nzt = (ez + t.zstep - 1) / t.zstep;
     t.mask = (ez % t.zstep) != 0 || (ey % t.tile_rows) != 0;
     t.fill = (double)ey * ez / ((double)t.nyt * t.tile_rows * t.nzt * t.zstep);
     return t;
   };
-  const M2Tiling w = make(true), n = make(false);
-  return w.fill >= n.fill ? w : n;
+  const int forced = env_int2("FDTD_FUSE2_TILE", 0);
+  if (forced == 512 || forced == 256 || forced == 128) return make(forced);
+  // Tiles of 512 or 256 cells: whichever fills better, the wider one on ties (fewer z-cuts, each of which
+  // costs a seam pass over four cells per row and plane).  Tiles of 128 cells are taken on request only
+  // (FDTD_FUSE2_TILE=128, or FDTD_FUSE2_NARROW_GAIN=g: when they fill better by g percent): measured on
+  // MI355X their sweep is about 10 % slower per cell than the 256-cell one and every additional cut costs
+  // 0.14 us per 1000 rows-times-planes, which eats the better fill — 384^3: 294 against 330 Gcells/s with
+  // masked 512-cell tiles, 640^3: 332 against 322, 520^3: 273 against 283, 768^3: 338 against 408.
+  M2Tiling best = make(M2_ZCELLS);
+  {
+    const M2Tiling t = make(M2_ZCELLS / 2);
+    if (t.fill > best.fill) best = t;
+  }
+  const int narrow_gain = env_int2("FDTD_FUSE2_NARROW_GAIN", 0);
+  if (narrow_gain > 0) {
+    const M2Tiling t = make(M2_ZCELLS / 4);
+    if (t.fill > best.fill * (1.0 + narrow_gain / 100.0)) best = t;
+  }
+  return best;
 }
 
 // Can the fused kernel take this problem?  (Everything else goes through two single sweeps.)
@@ -694,7 +762,6 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // 1024^3 at 372 instead of 437 Gcells/s).
   const int ez = g->z_M - g->z_m + 1;
   const M2Tiling tl = m2_tiling(ey, ez);
-  const bool wide = tl.wide;                                 // z-tiles of 512 cells, else of 256
   const int zstep = tl.zstep, nyt = tl.nyt, nzt = tl.nzt;
   const int ntile = nyt * nzt;
   // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
@@ -843,20 +910,23 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     for (long base = 0; base < total; base += per_launch) {
       const dim3 grid((unsigned)(total - base < per_launch ? total - base : per_launch)), block(512);
       const int b = (int)base;
-#define M2_LAUNCH(NT_, ZH_, MASK_)                                                                          \
+#define M2_LAUNCH(NT_, ZH_, MASK_, LPR_)                                                                    \
   do {                                                                                                       \
     if (dispatch_times)                                                                                      \
-      hipExtLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_>), grid, block, 0, s, ev_begin, ev_end, 0, a, \
-                            xchunk, nyt, nzt, b);                                                            \
+      hipExtLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_, LPR_>), grid, block, 0, s, ev_begin, ev_end, 0, \
+                            a, xchunk, nyt, nzt, b);                                                         \
     else                                                                                                     \
-      hipLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_>), grid, block, 0, s, a, xchunk, nyt, nzt, b); \
+      hipLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_, LPR_>), grid, block, 0, s, a, xchunk, nyt, nzt, b); \
   } while (0)
-      if (wide) {
-        if (tl.mask) { if (nt) M2_LAUNCH(true, 2, true); else M2_LAUNCH(false, 2, true); }
-        else { if (nt) M2_LAUNCH(true, 2, false); else M2_LAUNCH(false, 2, false); }
+      if (zstep == M2_ZCELLS) {
+        if (tl.mask) { if (nt) M2_LAUNCH(true, 2, true, 64); else M2_LAUNCH(false, 2, true, 64); }
+        else { if (nt) M2_LAUNCH(true, 2, false, 64); else M2_LAUNCH(false, 2, false, 64); }
+      } else if (zstep == M2_ZCELLS / 2) {
+        if (tl.mask) { if (nt) M2_LAUNCH(true, 1, true, 64); else M2_LAUNCH(false, 1, true, 64); }
+        else { if (nt) M2_LAUNCH(true, 1, false, 64); else M2_LAUNCH(false, 1, false, 64); }
       } else {
-        if (tl.mask) { if (nt) M2_LAUNCH(true, 1, true); else M2_LAUNCH(false, 1, true); }
-        else { if (nt) M2_LAUNCH(true, 1, false); else M2_LAUNCH(false, 1, false); }
+        if (tl.mask) { if (nt) M2_LAUNCH(true, 1, true, 32); else M2_LAUNCH(false, 1, true, 32); }
+        else { if (nt) M2_LAUNCH(true, 1, false, 32); else M2_LAUNCH(false, 1, false, 32); }
       }
 #undef M2_LAUNCH
       __atomic_add_fetch(&g_fused_launches, 1, __ATOMIC_RELAXED);

@@ -238,7 +238,8 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((24, 1, 256), 1, "march2"), ((30, 3, 520), 2, "march2"),
                                                 ((24, 2, 1028), 2, "march2"), ((30, 20, 516), 12, "march2"),
                                                 ((24, 5, 260), 10, "march2")])
-def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant, monkeypatch):
+@pytest.mark.parametrize("tile", ["", "128", "256"])
+def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant, tile, monkeypatch):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
     one launch, forced fusion on a short x range, rows of 256 cells (fused on request only), no
@@ -251,6 +252,9 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
     the masked variant of the kernel."""
     import torch
     monkeypatch.setenv("FDTD_FUSE2_MIN_CELLS", "0")   # the automatic choice would leave the small shapes alone
+    if tile:                                          # every shape through tiles of 128 / 256 cells as well
+        monkeypatch.setenv("FDTD_FUSE2_TILE", tile)
+        monkeypatch.setenv("FDTD_FUSE2_MIN_FILL", "0")
     nx, ny, nz = shape
     gen = torch.Generator(device="cuda").manual_seed(1234)
     pshape = (nx + 8, ny + 8, nz + 8)
@@ -360,12 +364,15 @@ def test_two_steps_rejects_overlapping_levels(pkg, hiplib):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
-def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, monkeypatch):
+@pytest.mark.parametrize("tile", ["", "128"])
+def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, tile, monkeypatch):
     """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s goes
     through the two-step sweep (masked tiles for all but the fused_z* shapes; with 27 and 30 sources the
     scatter and repair passes behind the sweep), the others through the ordinary loop; the bytes are the
     fixture's either way."""
     monkeypatch.setenv("FDTD_VARIANT", "march2")
+    if tile:
+        monkeypatch.setenv("FDTD_FUSE2_TILE", tile)
     c = cases.build(name, pkg)
     before = hiplib.fdtd_hip_fused_launch_count()
     rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
