@@ -87,6 +87,17 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = OPERATOR_ARGTYPES
         fn.restype = C.c_int
+    L.fdtd_hip_set_space_order.argtypes = [C.c_int]
+    L.fdtd_hip_set_space_order.restype = C.c_int
+    L.fdtd_hip_get_space_order.argtypes = []
+    L.fdtd_hip_get_space_order.restype = C.c_int
+    L.fdtd_hip_stencil_step_order.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_stencil_step_order.restype = C.c_int
+    L.fdtd_hip_source_inject_order.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_source_inject_order.restype = C.c_int
     L.fdtd_hip_multigpu_last_slab_count.argtypes = []
     L.fdtd_hip_multigpu_last_slab_count.restype = C.c_int
     L.fdtd_hip_release_device_copies.argtypes = []

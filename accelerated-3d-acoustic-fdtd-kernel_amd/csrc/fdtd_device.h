@@ -37,6 +37,7 @@ struct InjectArgs {
   int x_shift, x_lo, x_hi;
   int target_mode;  // 0: all admitted corners; 1: only those landing outside the domain's box; 2: only inside
   int gx_m, gx_M;   // planes of the domain's box in the coordinates of the source positions (target_mode != 0)
+  int halo;         // cells of padding per side of the arrays (FDTD_HALO; the space order for orders 6 and 8)
 };
 
 #define FDTD_HIP_CHECK(expr)                  \
@@ -53,6 +54,17 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
                       const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
                       int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
                       int gx_m, int gx_M, void *stream);
+
+// The scatter on arrays padded by `halo` cells per side (fdtd_inject_level is the case halo = FDTD_HALO).
+int fdtd_inject_level_halo(const struct fdtd_geom *g, const float *m, const float *src,
+                           const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
+                           int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
+                           int gx_m, int gx_M, int halo, void *stream);
+// fdtd_orders.hip: one sweep of space order 4, 6 or 8 on arrays padded by `order` cells per side.
+int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
+                              float *u2, int order, void *stream);
+
+extern "C" int fdtd_hip_get_space_order(void);
 
 // Sweep and scatter in one launch for small grids (fdtd_kernels.hip).
 struct FdtdSmallSource {

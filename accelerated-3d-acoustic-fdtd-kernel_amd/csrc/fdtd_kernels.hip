@@ -619,10 +619,10 @@ __global__ __launch_bounds__(256) void source_inject_kernel(InjectArgs a) {
       inject_target_selected(a, rx + posx, ry + posy, rz + posz)) {
     const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
                      (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
-                     a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
-                         (posz + FDTD_HALO)];
-    atomicAdd(a.u2 + (long)(rx + posx - a.x_shift + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
-                  (rz + posz + FDTD_HALO),
+                     a.m[(long)(posx - a.x_shift + a.halo) * a.sx + (long)(posy + a.halo) * a.sy +
+                         (posz + a.halo)];
+    atomicAdd(a.u2 + (long)(rx + posx - a.x_shift + a.halo) * a.sx + (long)(ry + posy + a.halo) * a.sy +
+                  (rz + posz + a.halo),
               r0);
   }
 }
@@ -653,10 +653,10 @@ __global__ __launch_bounds__(1024) void source_inject_ordered_kernel(InjectArgs 
         inject_target_selected(a, rx + posx, ry + posy, rz + posz)) {
       r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
            (rz * pz + (1 - rz) * (1 - pz)) * a.src[(long)a.time * a.src_stride + p] /
-           a.m[(long)(posx - a.x_shift + FDTD_HALO) * a.sx + (long)(posy + FDTD_HALO) * a.sy +
-               (posz + FDTD_HALO)];
-      cell = (long)(rx + posx - a.x_shift + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy +
-             (rz + posz + FDTD_HALO);
+           a.m[(long)(posx - a.x_shift + a.halo) * a.sx + (long)(posy + a.halo) * a.sy +
+               (posz + a.halo)];
+      cell = (long)(rx + posx - a.x_shift + a.halo) * a.sx + (long)(ry + posy + a.halo) * a.sy +
+             (rz + posz + a.halo);
     }
   }
   s_cell[tid] = cell;
@@ -1002,6 +1002,14 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
                       const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
                       int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
                       int gx_m, int gx_M, void *stream) {
+  return fdtd_inject_level_halo(g, m, src, src_coords, level, time, p_src_m, p_src_M, src_stride, coord_stride,
+                                x_shift, x_lo, x_hi, target_mode, gx_m, gx_M, FDTD_HALO, stream);
+}
+
+int fdtd_inject_level_halo(const struct fdtd_geom *g, const float *m, const float *src,
+                           const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
+                           int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
+                           int gx_m, int gx_M, int halo, void *stream) {
   if (p_src_M < p_src_m) return 0;
   if (!g || !m || !src || !src_coords || !level || coord_stride < 3 || src_stride < 1)
     return (int)hipErrorInvalidValue;
@@ -1011,6 +1019,7 @@ int fdtd_inject_level(const struct fdtd_geom *g, const float *m, const float *sr
   a.u2 = level;
   a.target_mode = target_mode;
   a.gx_m = gx_m; a.gx_M = gx_M;
+  a.halo = halo;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;

@@ -309,7 +309,9 @@ extern "C" int Kernel_HIP_MultiGPU(FDTD_OPERATOR_ARGS) {
   // else (a sub-range in x, a handful of planes, no time step at all) is one device's work.
   int nslab = (int)devices.size();
   if (NX / 8 < nslab) nslab = NX / 8;
-  const bool whole_x = x_m == 0 && x_M == NX - 1 && y_M >= y_m && z_M >= z_m && time_M >= time_m;
+  // (the slab kernels are written for space order 4; other orders run on one device)
+  const bool whole_x = x_m == 0 && x_M == NX - 1 && y_M >= y_m && z_M >= z_m && time_M >= time_m &&
+                       fdtd_hip_get_space_order() == FDTD_STENCIL_ORDER;
   g_multigpu_last_slabs = (nslab >= 2 && whole_x) ? nslab : 1;
   if (nslab < 2 || !whole_x)
     return Kernel_CUDA_Optimized(m_vec, src_vec, src_coords_vec, u_vec, x_M, x_m, y_M, y_m, z_M, z_m, dt, h_x, h_y, h_z,

@@ -310,6 +310,37 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
   hipStream_t s = (hipStream_t)stream;
   const bool has_src = (p_src_M >= p_src_m) && src && src_coords;
   if (p_src_M >= p_src_m && !has_src) return (int)hipErrorInvalidValue;
+  // Space orders 6 and 8 (fdtd_hip_set_space_order / FDTD_STENCIL_ORDER): arrays padded by `order` cells,
+  // one sweep and one scatter per step through the generic one-cell-per-thread kernel.
+  const int order = fdtd_hip_get_space_order();
+  if (order != FDTD_STENCIL_ORDER) {
+    if (h16) return (int)hipErrorInvalidValue;
+    const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
+    float *uf = (float *)u;
+    const int first_timed = time_m + FDTD_WARMUP_STEPS;
+    const int n_timed = (timers && time_M >= first_timed) ? (time_M - first_timed + 1) : 0;
+    SectionTimer st;
+    int rc = st.init(n_timed);
+    if (rc) return rc;
+    for (int time = time_m; time <= time_M; ++time) {
+      const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3, t2 = (((time + 1) % 3) + 3) % 3;
+      const int k = (n_timed > 0 && time >= first_timed) ? (time - first_timed) : -1;
+      if (st.at(k, 0)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 0), s));
+      rc = fdtd_stencil_levels_order(g, m, uf + t0 * vol, uf + t1 * vol, uf + t2 * vol, order, s);
+      if (rc) return rc;
+      if (st.at(k, 1)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 1), s));
+      if (has_src) {
+        rc = fdtd_inject_level_halo(g, m, src, src_coords, uf + t2 * vol, time, p_src_m, p_src_M, src_stride,
+                                    coord_stride, 0, g->x_m - 1, g->x_M + 1, 0, 0, 0, order, s);
+        if (rc) return rc;
+      }
+      if (st.at(k, 2)) FDTD_HIP_CHECK(hipEventRecord(st.at(k, 2), s));
+    }
+    if (st.window_end()) FDTD_HIP_CHECK(hipEventRecord(st.window_end(), s));
+    FDTD_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_timed > 0) return st.finish(timers);
+    return 0;
+  }
 
   // two steps per sweep when the shape allows it and there are enough steps to pay for the
   // extra level buffer
@@ -717,7 +748,8 @@ typedef int (*operator_fn)(FDTD_OPERATOR_ARGS);
 static int run_standard(operator_fn op, int NX, int NY, int NZ, int nt, int nsrc, float *u_out,
                         float *max_abs_u, struct profiler *timers) {
   if (NX <= 0 || NY <= 0 || NZ <= 0 || nt <= 0 || nsrc < 0) return (int)hipErrorInvalidValue;
-  const int nxp = NX + 2 * FDTD_HALO, nyp = NY + 2 * FDTD_HALO, nzp = NZ + 2 * FDTD_HALO;
+  const int halo = fdtd_hip_get_space_order();   // HALO = STENCIL_ORDER (main.cpp:32)
+  const int nxp = NX + 2 * halo, nyp = NY + 2 * halo, nzp = NZ + 2 * halo;
   const size_t volp = (size_t)nxp * nyp * nzp;
   std::vector<float> u(3 * volp, 0.0f), m(volp, 1.5f);
   std::vector<float> src((size_t)nt * (nsrc > 0 ? nsrc : 1)), coords((size_t)(nsrc > 0 ? nsrc : 1) * 3);

@@ -122,6 +122,24 @@ void fdtd_hip_release_device_copies(void);
  * device, time loop, copy to the host. */
 void fdtd_hip_last_call_phases(double out_ms[4]);
 
+/* Space order of the operators and of fdtd_hip_time_loop: 4 (default), 6 or 8.  The reference driver
+ * is parameterised on STENCIL_ORDER with HALO = STENCIL_ORDER cells of padding per side
+ * (main.cpp:27-32,129-136): a driver built with -DSTENCIL_ORDER=8 hands over arrays padded by 8 cells
+ * and interior cell i lives at padded index i + 8.  No reference kernel implements any order but 4
+ * (openacc.cpp:102-107), so orders 6 and 8 have no reference arithmetic (parity unpinned): they
+ * evaluate the order-4 expression of openacc.cpp:159-164 with the central second-difference weights
+ * of their order (9-digit float literals, farthest neighbours first), through a one-cell-per-thread
+ * kernel.  The order is process-wide: set it before the operators are called (or export
+ * FDTD_STENCIL_ORDER); fp16 storage, the two-step sweep and the multi-GPU operator exist for order 4 only. */
+int fdtd_hip_set_space_order(int order);
+int fdtd_hip_get_space_order(void);
+/* One sweep / one scatter of a given space order on arrays padded by `order` cells per side. */
+int fdtd_hip_stencil_step_order(const struct fdtd_geom *g, const float *m, float *u, int t0, int t1,
+                                int t2, int order, void *stream);
+int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const float *m, const float *src,
+                                 const float *src_coords, float *u, int t2, int time, int p_src_m,
+                                 int p_src_M, int src_stride, int coord_stride, int order, void *stream);
+
 /* Optional hook the reference driver looks up as a weak symbol and calls once per
  * benchmark sweep (main.cpp:84,266-276).  The call records the values and returns.
  * t_fuse >= 2 makes Kernel_CUDA_Optimized take the two-steps-per-sweep kernel whatever

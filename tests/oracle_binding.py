@@ -39,6 +39,8 @@ def oracle():
         L.oracle_source_inject_slab.restype = None
         L.oracle_source_inject_slab_mode.argtypes = L.oracle_source_inject_slab.argtypes + [C.c_int] * 3
         L.oracle_source_inject_slab_mode.restype = None
+        L.Oracle_Kernel_SpaceOrder.argtypes = pkg.abi.OPERATOR_ARGTYPES + [C.c_int]
+        L.Oracle_Kernel_SpaceOrder.restype = C.c_int
         L.oracle_compare_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(pkg.Parity)]
         L.oracle_compare_fields.restype = None
@@ -66,6 +68,19 @@ def run_oracle(m, src, coords, u, **kw):
     """Oracle_Kernel_OpenACC with the same keyword interface as pkg.run_operator."""
     pkg = load_package()
     rc, prof = pkg.run_operator(oracle().Oracle_Kernel_OpenACC, m, src, coords, u, **kw)
+    assert rc == 0
+    return prof
+
+
+def run_oracle_order(order, m, src, coords, u, **kw):
+    """The oracle for space order 4, 6 or 8 (arrays padded by `order` cells per side); keyword interface of
+    pkg.run_operator except that `bounds` is required when the padding is not 4."""
+    pkg = load_package()
+    fn = oracle().Oracle_Kernel_SpaceOrder
+
+    def call(*args):
+        return fn(*args, order)
+    rc, prof = pkg.run_operator(call, m, src, coords, u, **kw)
     assert rc == 0
     return prof
 
