@@ -133,13 +133,6 @@ void fdtd_hip_last_call_phases(double out_ms[4]);
  * FDTD_STENCIL_ORDER); fp16 storage, the two-step sweep and the multi-GPU operator exist for order 4 only. */
 int fdtd_hip_set_space_order(int order);
 int fdtd_hip_get_space_order(void);
-/* One sweep / one scatter of a given space order on arrays padded by `order` cells per side. */
-int fdtd_hip_stencil_step_order(const struct fdtd_geom *g, const float *m, float *u, int t0, int t1,
-                                int t2, int order, void *stream);
-int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const float *m, const float *src,
-                                 const float *src_coords, float *u, int t2, int time, int p_src_m,
-                                 int p_src_M, int src_stride, int coord_stride, int order, void *stream);
-
 /* Optional hook the reference driver looks up as a weak symbol and calls once per
  * benchmark sweep (main.cpp:84,266-276).  The call records the values and returns.
  * t_fuse >= 2 makes Kernel_CUDA_Optimized take the two-steps-per-sweep kernel whatever
@@ -172,6 +165,13 @@ struct fdtd_geom {
   float dt, h_x, h_y, h_z;    /* time step and grid spacings                        */
   float o_x, o_y, o_z;        /* grid origin                                        */
 };
+
+/* One sweep / one scatter of a given space order on arrays padded by `order` cells per side. */
+int fdtd_hip_stencil_step_order(const struct fdtd_geom *g, const float *m, float *u, int t0, int t1,
+                                int t2, int order, void *stream);
+int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const float *m, const float *src,
+                                 const float *src_coords, float *u, int t2, int time, int p_src_m,
+                                 int p_src_M, int src_stride, int coord_stride, int order, void *stream);
 
 /* One leapfrog update  u[t2] <- stencil(u[t0], u[t1], m)  over the ranges in g.
  * Replaces one launch of stencil_update_kernel_1step (cuda.cu:237-243) /
