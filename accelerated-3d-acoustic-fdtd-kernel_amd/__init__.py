@@ -22,6 +22,7 @@ from .abi import (  # noqa: F401
     lib,
     lib_path,
     make_dataobj,
+    run_forward,
     run_operator,
     standard_inputs,
 )

@@ -61,6 +61,10 @@ OPERATOR_ARGTYPES = (
     + [C.POINTER(Profiler)]
 )
 
+# Kernel_HIP_Forward: damp, m, rec, rec_coords, src, src_coords, u; bounds; dt, h, o; p_rec, p_src, time; device; timers
+FORWARD_ARGTYPES = ([C.POINTER(Dataobj)] * 7 + [C.c_int] * 6 + [C.c_float] * 7 + [C.c_int] * 8
+                    + [C.POINTER(Profiler)])
+
 _lib = None
 
 
@@ -87,6 +91,14 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = OPERATOR_ARGTYPES
         fn.restype = C.c_int
+    L.Kernel_HIP_Forward.argtypes = FORWARD_ARGTYPES
+    L.Kernel_HIP_Forward.restype = C.c_int
+    L.fdtd_hip_stencil_step_damped.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_int, C.c_void_p]
+    L.fdtd_hip_stencil_step_damped.restype = C.c_int
+    L.fdtd_hip_receiver_sample.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_receiver_sample.restype = C.c_int
     L.fdtd_hip_set_space_order.argtypes = [C.c_int]
     L.fdtd_hip_set_space_order.restype = C.c_int
     L.fdtd_hip_get_space_order.argtypes = []
@@ -220,6 +232,35 @@ def run_operator(fn, m, src, coords, u, *, bounds=None, dt=1e-3, h=(0.1, 0.1, 0.
     rc = fn(C.byref(md), C.byref(sd), C.byref(cd), C.byref(ud),
             x_M, x_m, y_M, y_m, z_M, z_m, dt, h[0], h[1], h[2], o[0], o[1], o[2],
             p_src[1], p_src[0], time_M, time_m, deviceid, devicerm, C.byref(prof))
+    del keep
+    return rc, prof
+
+
+def run_forward(fn, damp, m, rec, rec_coords, src, coords, u, *, bounds=None, dt=1e-3, h=(0.1, 0.1, 0.1),
+                o=(0.0, 0.0, 0.0), time_m=0, time_M=None, deviceid=0):
+    """Call a forward operator (Kernel_HIP_Forward or the oracle's) on numpy arrays; `rec` is [T][nrec] (written),
+    `rec_coords` [nrec][3], or both None."""
+    nxp, nyp, nzp = u.shape[1:]
+    if bounds is None:
+        bounds = (0, nxp - 2 * HALO - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1)
+    x_m, x_M, y_m, y_M, z_m, z_M = bounds
+    keep = []
+
+    def wrap(arr, empty_sizes):
+        d, k = make_dataobj(arr, None if arr is not None else empty_sizes)
+        keep.append(k)
+        return d
+    dd, md, ud = wrap(damp, None), wrap(m, None), wrap(u, None)
+    rd, rcd = wrap(rec, (0, 1)), wrap(rec_coords, (2, 0))
+    sd, scd = wrap(src, (0, 1)), wrap(coords, (2, 0))
+    p_rec = (0, rec.shape[1] - 1) if rec is not None else (0, -1)
+    p_src = (0, src.shape[1] - 1) if src is not None else (0, -1)
+    if time_M is None:
+        time_M = (src if src is not None else rec).shape[0] - 1
+    prof = Profiler(0.0, 0.0)
+    rc = fn(C.byref(dd), C.byref(md), C.byref(rd), C.byref(rcd), C.byref(sd), C.byref(scd), C.byref(ud),
+            x_M, x_m, y_M, y_m, z_M, z_m, dt, h[0], h[1], h[2], o[0], o[1], o[2],
+            p_rec[1], p_rec[0], p_src[1], p_src[0], time_M, time_m, deviceid, 1, C.byref(prof))
     del keep
     return rc, prof
 

@@ -1,0 +1,245 @@
+// fdtd_forward.hip — the steps either side of the hot path in a Devito-style propagator: an absorbing
+// sponge (damping field) in the update and receivers that sample the wavefield (Kernel_HIP_Forward).
+//
+// The reference has neither: its halo is a fixed frame and nothing reads the field during the run
+// (main.cpp:352 `m = 1.5`, openacc.cpp:148-205 has two sections only).  There is therefore no reference
+// arithmetic for this file: parity unpinned.  The forms are chosen so that they degenerate to the
+// reference's: the damped update is openacc.cpp:159-164 with a first-order damping term,
+//     m (u+ - 2u + u-)/dt^2 + damp (u+ - u)/dt = lap(u)
+//     u+ = dt^2 ( lap - (-2 r1 u + r1 u-) m + r0 damp u ) / (m + dt damp),        r0 = 1/dt, r1 = 1/dt^2
+// (damp = 0: the reference expression), and the receiver interpolation is the transpose of the scatter of
+// openacc.cpp:185-196 (same positions, weights, loop order and bounds test; a corner outside the bounds
+// contributes nothing).  Receivers sample the level the step started from, u(time), as a generated
+// Devito operator does.  One cell per thread / one receiver per thread; the register- and LDS-staged
+// sweeps serve the undamped update only.
+#include <math.h>
+
+#include <vector>
+
+#include "fdtd_device.h"
+#include "fdtd_host.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__constant__ float fw_c_m2 = -8.33333333e-2F, fw_c_m1 = 1.333333330F, fw_c_0 = -2.50F;
+
+struct DampedArgs {
+  StencilArgs s;
+  const float *damp;
+  float dt, r0;
+};
+
+__global__ __launch_bounds__(256) void stencil_damped_kernel(DampedArgs a) {
+  const StencilArgs &s = a.s;
+  const int z = s.z_m + blockIdx.x * 64 + threadIdx.x;
+  const int y = s.y_m + blockIdx.y * 4 + threadIdx.y;
+  const int x = s.x_m + blockIdx.z;
+  if (z > s.z_M || y > s.y_M) return;
+  const long sx = s.sx, sy = s.sy;
+  const long c = (long)(x + FDTD_HALO) * sx + (long)(y + FDTD_HALO) * sy + (z + FDTD_HALO);
+  const float *__restrict__ u0 = s.u0;
+  const float uc = u0[c];
+  const float r5 = fw_c_0 * uc;
+  const float dxx = r5 + fw_c_m2 * (u0[c - 2 * sx] + u0[c + 2 * sx]) + fw_c_m1 * (u0[c - sx] + u0[c + sx]);
+  const float dyy = r5 + fw_c_m2 * (u0[c - 2 * sy] + u0[c + 2 * sy]) + fw_c_m1 * (u0[c - sy] + u0[c + sy]);
+  const float dzz = r5 + fw_c_m2 * (u0[c - 2] + u0[c + 2]) + fw_c_m1 * (u0[c - 1] + u0[c + 1]);
+  const float mc = s.m[c], dc = a.damp[c];
+  const float neg2r1 = -2.0F * s.r1;
+  s.u2[c] = s.dt2 * (s.r2 * dxx + s.r3 * dyy + s.r4 * dzz - (neg2r1 * uc + s.r1 * s.u1[c]) * mc + a.r0 * dc * uc) /
+            (mc + a.dt * dc);
+}
+
+struct ReceiverArgs {
+  const float *u, *coords;
+  float *rec_row;    // rec + time * rec_stride
+  long sx, sy;
+  int x_m, x_M, y_m, y_M, z_m, z_M;
+  float h_x, h_y, h_z, o_x, o_y, o_z;
+  int p_rec_m, p_rec_M, coord_stride;
+};
+
+__global__ __launch_bounds__(256) void receiver_kernel(ReceiverArgs a) {
+  const int p = a.p_rec_m + blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > a.p_rec_M) return;
+  const float gx = (-a.o_x + a.coords[(long)p * a.coord_stride + 0]) / a.h_x;
+  const float gy = (-a.o_y + a.coords[(long)p * a.coord_stride + 1]) / a.h_y;
+  const float gz = (-a.o_z + a.coords[(long)p * a.coord_stride + 2]) / a.h_z;
+  const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
+  const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
+  float sum = 0.0F;
+  for (int rx = 0; rx <= 1; ++rx)
+    for (int ry = 0; ry <= 1; ++ry)
+      for (int rz = 0; rz <= 1; ++rz)
+        if (rx + posx >= a.x_m - 1 && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 && rx + posx <= a.x_M + 1 &&
+            ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1)
+          sum += (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) * (rz * pz + (1 - rz) * (1 - pz)) *
+                 a.u[(long)(rx + posx + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy + (rz + posz + FDTD_HALO)];
+  a.rec_row[p] = sum;
+}
+
+struct Buffers {
+  std::vector<void *> p;
+  ~Buffers() {
+    for (void *q : p)
+      if (q) (void)hipFree(q);
+  }
+  int alloc(void **out, size_t bytes) {
+    FDTD_HIP_CHECK(hipMalloc(out, bytes ? bytes : 4));
+    p.push_back(*out);
+    return 0;
+  }
+};
+
+}  // namespace
+
+// One damped sweep on explicit level pointers (damp has the padded shape of m).
+extern "C" int fdtd_hip_stencil_step_damped(const struct fdtd_geom *g, const float *m, const float *damp, float *u,
+                                            int t0, int t1, int t2, void *stream) {
+  if (!g || !m || !damp || !u || t0 < 0 || t0 > 2 || t1 < 0 || t1 > 2 || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
+  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
+  if (ex <= 0 || ey <= 0 || ez <= 0) return 0;
+  if (g->x_m + FDTD_HALO - 2 < 0 || g->x_M + FDTD_HALO + 2 > g->nxp - 1 || g->y_m + FDTD_HALO - 2 < 0 ||
+      g->y_M + FDTD_HALO + 2 > g->nyp - 1 || g->z_m + FDTD_HALO - 2 < 0 || g->z_M + FDTD_HALO + 2 > g->nzp - 1)
+    return (int)hipErrorInvalidValue;
+  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
+  const long vol = (long)g->nxp * g->nyp * g->nzp;
+  DampedArgs a;
+  a.s.m = m; a.s.u0 = u + t0 * vol; a.s.u1 = u + t1 * vol; a.s.u2 = u + t2 * vol;
+  a.s.sx = (long)g->nyp * g->nzp; a.s.sy = g->nzp;
+  a.s.nxp = g->nxp; a.s.nyp = g->nyp; a.s.nzp = g->nzp;
+  a.s.x_m = g->x_m; a.s.x_M = g->x_M; a.s.y_m = g->y_m; a.s.y_M = g->y_M; a.s.z_m = g->z_m; a.s.z_M = g->z_M;
+  a.s.dt2 = g->dt * g->dt;
+  a.s.r1 = 1.0F / (g->dt * g->dt);
+  a.s.r2 = 1.0F / (g->h_x * g->h_x);
+  a.s.r3 = 1.0F / (g->h_y * g->h_y);
+  a.s.r4 = 1.0F / (g->h_z * g->h_z);
+  a.damp = damp; a.dt = g->dt; a.r0 = 1.0F / g->dt;
+  hipLaunchKernelGGL(stencil_damped_kernel, dim3((ez + 63) / 64, (ey + 3) / 4, ex), dim3(64, 4, 1), 0,
+                     (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// rec[time][p] = trilinear interpolation of level t of u at rec_coords[p], p = p_rec_m .. p_rec_M.
+extern "C" int fdtd_hip_receiver_sample(const struct fdtd_geom *g, const float *u, int t, const float *rec_coords,
+                                        float *rec, int time, int p_rec_m, int p_rec_M, int rec_stride,
+                                        int coord_stride, void *stream) {
+  if (p_rec_M < p_rec_m) return 0;
+  if (!g || !u || !rec_coords || !rec || t < 0 || t > 2 || rec_stride < 1 || coord_stride < 3 || time < 0)
+    return (int)hipErrorInvalidValue;
+  ReceiverArgs a;
+  a.u = u + (long)t * g->nxp * g->nyp * g->nzp;
+  a.coords = rec_coords;
+  a.rec_row = rec + (long)time * rec_stride;
+  a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
+  a.x_m = g->x_m; a.x_M = g->x_M; a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
+  a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
+  a.p_rec_m = p_rec_m; a.p_rec_M = p_rec_M; a.coord_stride = coord_stride;
+  const int n = p_rec_M - p_rec_m + 1;
+  hipLaunchKernelGGL(receiver_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// The forward operator of a Devito-style acoustic propagator: damped update, source scatter, receiver
+// sampling, per time step.  Host arrays in, u and rec out; argument conventions of the operator ABI
+// (max before min, inclusive ranges, timers accumulated over steps time_m+5 .. time_M; section0 = update,
+// section1 = scatter and receivers).
+extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
+                                  struct dataobj *rec_coords_vec, struct dataobj *src_vec,
+                                  struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M, const int x_m,
+                                  const int y_M, const int y_m, const int z_M, const int z_m, const float dt,
+                                  const float h_x, const float h_y, const float h_z, const float o_x, const float o_y,
+                                  const float o_z, const int p_rec_M, const int p_rec_m, const int p_src_M,
+                                  const int p_src_m, const int time_M, const int time_m, const int deviceid,
+                                  const int devicerm, struct profiler *timers) {
+  (void)devicerm;
+  if (!damp_vec || !rec_vec || !rec_coords_vec) return (int)hipErrorInvalidValue;
+  int rc = fdtd_check_operator_args(m_vec, src_vec, src_coords_vec, u_vec, p_src_M, p_src_m);
+  if (rc) return rc;
+  if (fdtd_hip_get_space_order() != FDTD_STENCIL_ORDER) return (int)hipErrorInvalidValue;
+  if (!damp_vec->data || !damp_vec->size) return (int)hipErrorInvalidValue;
+  for (int d = 0; d < 3; ++d)
+    if (damp_vec->size[d] != m_vec->size[d]) return (int)hipErrorInvalidValue;
+  const bool has_rec = p_rec_M >= p_rec_m;
+  if (has_rec) {
+    if (!rec_vec->data || !rec_vec->size || !rec_coords_vec->data || !rec_coords_vec->size) return (int)hipErrorInvalidValue;
+    if (p_rec_m < 0 || p_rec_M >= rec_vec->size[1] || p_rec_M >= rec_coords_vec->size[0] || rec_coords_vec->size[1] < 3 ||
+        time_m < 0 || time_M >= rec_vec->size[0])
+      return (int)hipErrorInvalidValue;
+  }
+  const bool has_src = p_src_M >= p_src_m && (long)src_vec->size[0] * src_vec->size[1] > 0;
+  if (has_src && (time_M >= src_vec->size[0] || time_m < 0)) return (int)hipErrorInvalidValue;
+  if (deviceid != -1) FDTD_HIP_CHECK(hipSetDevice(deviceid));
+
+  fdtd_geom g;
+  g.nxp = u_vec->size[1]; g.nyp = u_vec->size[2]; g.nzp = u_vec->size[3];
+  g.x_m = x_m; g.x_M = x_M; g.y_m = y_m; g.y_M = y_M; g.z_m = z_m; g.z_M = z_M;
+  g.dt = dt; g.h_x = h_x; g.h_y = h_y; g.h_z = h_z; g.o_x = o_x; g.o_y = o_y; g.o_z = o_z;
+  const size_t vol = (size_t)g.nxp * g.nyp * g.nzp;
+  const size_t n_src = has_src ? (size_t)src_vec->size[0] * src_vec->size[1] : 0;
+  const size_t n_sc = has_src ? (size_t)src_coords_vec->size[0] * src_coords_vec->size[1] : 0;
+  const size_t n_rec = has_rec ? (size_t)rec_vec->size[0] * rec_vec->size[1] : 0;
+  const size_t n_rc = has_rec ? (size_t)rec_coords_vec->size[0] * rec_coords_vec->size[1] : 0;
+
+  Buffers buf;
+  float *d_u, *d_m, *d_damp, *d_src = nullptr, *d_sc = nullptr, *d_rec = nullptr, *d_rc = nullptr;
+  if ((rc = buf.alloc((void **)&d_u, 3 * vol * sizeof(float)))) return rc;
+  if ((rc = buf.alloc((void **)&d_m, vol * sizeof(float)))) return rc;
+  if ((rc = buf.alloc((void **)&d_damp, vol * sizeof(float)))) return rc;
+  StagedCopier copier;
+  if ((rc = copier.to_device(d_u, u_vec->data, 3 * vol * sizeof(float)))) return rc;
+  if ((rc = copier.to_device(d_m, m_vec->data, vol * sizeof(float)))) return rc;
+  if ((rc = copier.to_device(d_damp, damp_vec->data, vol * sizeof(float)))) return rc;
+  if (has_src) {
+    if ((rc = buf.alloc((void **)&d_src, n_src * sizeof(float)))) return rc;
+    if ((rc = buf.alloc((void **)&d_sc, n_sc * sizeof(float)))) return rc;
+    FDTD_HIP_CHECK(hipMemcpy(d_src, src_vec->data, n_src * sizeof(float), hipMemcpyHostToDevice));
+    FDTD_HIP_CHECK(hipMemcpy(d_sc, src_coords_vec->data, n_sc * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (has_rec) {
+    if ((rc = buf.alloc((void **)&d_rec, n_rec * sizeof(float)))) return rc;
+    if ((rc = buf.alloc((void **)&d_rc, n_rc * sizeof(float)))) return rc;
+    FDTD_HIP_CHECK(hipMemcpy(d_rec, rec_vec->data, n_rec * sizeof(float), hipMemcpyHostToDevice));
+    FDTD_HIP_CHECK(hipMemcpy(d_rc, rec_coords_vec->data, n_rc * sizeof(float), hipMemcpyHostToDevice));
+  }
+
+  const int first_timed = time_m + FDTD_WARMUP_STEPS;
+  const int n_timed = (timers && time_M >= first_timed) ? (time_M - first_timed + 1) : 0;
+  std::vector<hipEvent_t> ev((size_t)n_timed * 3, nullptr);
+  struct EvGuard {
+    std::vector<hipEvent_t> &e;
+    ~EvGuard() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+  } guard{ev};
+  for (hipEvent_t &e : ev) FDTD_HIP_CHECK(hipEventCreate(&e));
+  hipStream_t s = nullptr;
+  for (int time = time_m; time <= time_M; ++time) {
+    const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3, t2 = (((time + 1) % 3) + 3) % 3;
+    const int k = (n_timed > 0 && time >= first_timed) ? time - first_timed : -1;
+    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3], s));
+    if ((rc = fdtd_hip_stencil_step_damped(&g, d_m, d_damp, d_u, t0, t1, t2, s))) return rc;
+    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 1], s));
+    if (has_src &&
+        (rc = fdtd_hip_source_inject(&g, d_m, d_src, d_sc, d_u, t2, time, p_src_m, p_src_M, src_vec->size[1],
+                                     src_coords_vec->size[1], s)))
+      return rc;
+    if (has_rec && (rc = fdtd_hip_receiver_sample(&g, d_u, t0, d_rc, d_rec, time, p_rec_m, p_rec_M, rec_vec->size[1],
+                                                  rec_coords_vec->size[1], s)))
+      return rc;
+    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 2], s));
+  }
+  FDTD_HIP_CHECK(hipStreamSynchronize(s));
+  for (int k = 0; k < n_timed; ++k) {
+    float a = 0.f, b = 0.f;
+    FDTD_HIP_CHECK(hipEventElapsedTime(&a, ev[(size_t)k * 3], ev[(size_t)k * 3 + 1]));
+    FDTD_HIP_CHECK(hipEventElapsedTime(&b, ev[(size_t)k * 3 + 1], ev[(size_t)k * 3 + 2]));
+    timers->section0 += a * 1e-3;
+    timers->section1 += b * 1e-3;
+  }
+  if ((rc = copier.to_host(u_vec->data, d_u, 3 * vol * sizeof(float)))) return rc;
+  if (has_rec) FDTD_HIP_CHECK(hipMemcpy(rec_vec->data, d_rec, n_rec * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}

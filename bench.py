@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--self-exchange", action="store_true",
                     help="N=1 rehearsal of the N>1 schedule: the rank is its own two neighbours, RCCL messages "
                          "included (measures what the exchange costs next to the interior sweep; not the headline)")
+    ap.add_argument("--velocity", default="constant", choices=["constant", "layered"],
+                    help="N=1: m = 1.5 everywhere (the reference's benchmark input, main.cpp:352) or five horizontal "
+                         "layers of velocity 1.5 .. 4.5 (m = 1/v^2): same kernels, heterogeneous medium")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="oracle steps for the CPU baseline sample")
     return ap.parse_args()
@@ -322,6 +325,9 @@ def main():
     else:
         ranks_seen = 1
         u, m, src, coords = pkg.standard_inputs(n, n, n, total_steps, 1)
+        if args.velocity == "layered":
+            v = 1.5 + 0.75 * np.minimum(4, (np.arange(m.shape[2]) * 5) // m.shape[2])
+            m[:] = (1.0 / (v * v)).astype(np.float32)[None, None, :]
         u_d = torch.from_numpy(u).to(dev)
         m_d = torch.from_numpy(m).to(dev)
         s_d = torch.from_numpy(src).to(dev)
@@ -486,7 +492,8 @@ def main():
             pass
     if not slabs:
         wl = (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
-              f"{total_steps} steps ({W} untimed)")
+              f"{total_steps} steps ({W} untimed)"
+              + (", five velocity layers 1.5 .. 4.5" if args.velocity == "layered" else ""))
     else:
         NX = int(cells_per_step / n / n)
         wl = (f"{NX}x{n}x{n} fp32 as {world} x-slabs, "

@@ -133,6 +133,24 @@ void fdtd_hip_last_call_phases(double out_ms[4]);
  * FDTD_STENCIL_ORDER); fp16 storage, the two-step sweep and the multi-GPU operator exist for order 4 only. */
 int fdtd_hip_set_space_order(int order);
 int fdtd_hip_get_space_order(void);
+/* The forward operator of a Devito-style acoustic propagator around the same path: the update with an
+ * absorbing sponge (damp, padded shape of m), the source scatter, and receivers that sample the wavefield
+ * (rec[time][p] at rec_coords[p][3], trilinear, the level the step starts from).  The reference has
+ * neither sponge nor receivers (fixed halo frame, main.cpp:352; two sections only, openacc.cpp:148-205),
+ * so there is no reference arithmetic for this entry: parity unpinned.  With damp = 0 the update is the
+ * expression of openacc.cpp:159-164; the interpolation is the transpose of the scatter of
+ * openacc.cpp:185-196.  Argument conventions of the operator ABI; p_rec_M < p_rec_m: no receivers.
+ * Space order 4 only; one-cell-per-thread kernels. */
+int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
+                       struct dataobj *rec_coords_vec, struct dataobj *src_vec,
+                       struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,
+                       const int x_m, const int y_M, const int y_m, const int z_M, const int z_m,
+                       const float dt, const float h_x, const float h_y, const float h_z,
+                       const float o_x, const float o_y, const float o_z, const int p_rec_M,
+                       const int p_rec_m, const int p_src_M, const int p_src_m, const int time_M,
+                       const int time_m, const int deviceid, const int devicerm,
+                       struct profiler *timers);
+
 /* Optional hook the reference driver looks up as a weak symbol and calls once per
  * benchmark sweep (main.cpp:84,266-276).  The call records the values and returns.
  * t_fuse >= 2 makes Kernel_CUDA_Optimized take the two-steps-per-sweep kernel whatever
@@ -172,6 +190,14 @@ int fdtd_hip_stencil_step_order(const struct fdtd_geom *g, const float *m, float
 int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const float *m, const float *src,
                                  const float *src_coords, float *u, int t2, int time, int p_src_m,
                                  int p_src_M, int src_stride, int coord_stride, int order, void *stream);
+
+/* The two device kernels Kernel_HIP_Forward adds to the path, on device arrays: one damped sweep, and
+ * the receiver interpolation of level t of u into rec[time][p_rec_m..p_rec_M]. */
+int fdtd_hip_stencil_step_damped(const struct fdtd_geom *g, const float *m, const float *damp, float *u,
+                                 int t0, int t1, int t2, void *stream);
+int fdtd_hip_receiver_sample(const struct fdtd_geom *g, const float *u, int t, const float *rec_coords,
+                             float *rec, int time, int p_rec_m, int p_rec_M, int rec_stride,
+                             int coord_stride, void *stream);
 
 /* One leapfrog update  u[t2] <- stencil(u[t0], u[t1], m)  over the ranges in g.
  * Replaces one launch of stencil_update_kernel_1step (cuda.cu:237-243) /

@@ -41,6 +41,8 @@ def oracle():
         L.oracle_source_inject_slab_mode.restype = None
         L.Oracle_Kernel_SpaceOrder.argtypes = pkg.abi.OPERATOR_ARGTYPES + [C.c_int]
         L.Oracle_Kernel_SpaceOrder.restype = C.c_int
+        L.Oracle_Kernel_Forward.argtypes = pkg.abi.FORWARD_ARGTYPES
+        L.Oracle_Kernel_Forward.restype = C.c_int
         L.oracle_compare_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(pkg.Parity)]
         L.oracle_compare_fields.restype = None
