@@ -876,6 +876,95 @@ __global__ __launch_bounds__(256) void stencil_small_kernel(StencilArgs a, const
   a.u2[c] = v;
 }
 
+// Small and medium grids, rows packed into waves: one lane = one float4 (4 cells in z) of one (x, y)
+// row, a wave = 64 / LPR rows of LPR float4s each, a workgroup = 4 waves on consecutive rows of one
+// plane; nothing loops.  With LPR = 32 (16) rows of 128 (64) cells fill every lane, where the
+// one-cell-per-thread kernel needs four times the waves and fifteen scalar loads per cell.  The nine
+// float4 of u0 a lane needs in x and y are aligned 16-byte loads, the z-neighbours come from the
+// adjacent lanes (DPP) or, at the ends of a row, from 8-byte edge loads; lanes beyond the end of a
+// row repeat its last float4 and store nothing.  The source corners are added by the lane that owns
+// their cell, in source order, exactly as stencil_small_kernel does.
+template <int LPR>
+__global__ __launch_bounds__(256) void stencil_rows_kernel(StencilArgs a, const FdtdSmallSource *__restrict__ tab,
+                                                           const float *__restrict__ src_row, int nsrc) {
+  constexpr int RPW = 64 / LPR;   // rows per wave
+  const int lane = threadIdx.x & 63;
+  const int zl = lane % LPR;
+  const int wave = threadIdx.x >> 6;
+  const int y = a.y_m + ((int)blockIdx.y * 4 + wave) * RPW + lane / LPR;
+  const int x = a.x_m + (int)blockIdx.z;
+  const int zfirst = a.z_m + ((int)blockIdx.x * LPR + zl) * 4;
+  const bool owned = zfirst <= a.z_M && y <= a.y_M;
+  const int zload = min(zfirst, a.z_M - 3), yload = min(y, a.y_M);
+  const bool first = zl == 0, last = zl == LPR - 1 || zfirst + 4 > a.z_M;
+  const Coef k = load_coef(a);
+  const long sx = a.sx, sy = a.sy;
+  const long c0 = (long)(x + FDTD_HALO) * sx + (long)(yload + FDTD_HALO) * sy + (zload + FDTD_HALO);
+  const float *__restrict__ u0 = a.u0;
+#define ROW4(off) (*reinterpret_cast<const float4 *>(u0 + c0 + (off)))
+  float4 c = ROW4(0);
+  const float4 xm2 = ROW4(-2 * sx), xm1 = ROW4(-sx), xp1 = ROW4(sx), xp2 = ROW4(2 * sx);
+  const float4 ym2 = ROW4(-2 * sy), ym1 = ROW4(-sy), yp1 = ROW4(sy), yp2 = ROW4(2 * sy);
+#undef ROW4
+  const float4 up = *reinterpret_cast<const float4 *>(a.u1 + c0);
+  const float4 mc = *reinterpret_cast<const float4 *>(a.m + c0);
+  // every lane issues both edge loads (no memory instruction under a divergent branch); only the
+  // first and the last lane of a row use them
+  const float2 eL = *reinterpret_cast<const float2 *>(u0 + c0 - 2);
+  const float2 eR = *reinterpret_cast<const float2 *>(u0 + c0 + 4);
+  asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w));
+  float lz = dpp_from_prev_lane(eL.x, c.z), lw = dpp_from_prev_lane(eL.y, c.w);
+  float rx = dpp_from_next_lane(eR.x, c.x), ry = dpp_from_next_lane(eR.y, c.y);
+  lz = first ? eL.x : lz; lw = first ? eL.y : lw;
+  rx = last ? eR.x : rx; ry = last ? eR.y : ry;
+  float o[4];
+  o[0] = update_cell(k, c.x, xm2.x, xm1.x, xp1.x, xp2.x, ym2.x, ym1.x, yp1.x, yp2.x, lz, lw, c.y, c.z, up.x, mc.x);
+  o[1] = update_cell(k, c.y, xm2.y, xm1.y, xp1.y, xp2.y, ym2.y, ym1.y, yp1.y, yp2.y, lw, c.x, c.z, c.w, up.y, mc.y);
+  o[2] = update_cell(k, c.z, xm2.z, xm1.z, xp1.z, xp2.z, ym2.z, ym1.z, yp1.z, yp2.z, c.x, c.y, c.w, rx, up.z, mc.z);
+  o[3] = update_cell(k, c.w, xm2.w, xm1.w, xp1.w, xp2.w, ym2.w, ym1.w, yp1.w, yp2.w, c.y, c.z, rx, ry, up.w, mc.w);
+  for (int i = 0; i < nsrc; ++i) {   // wave-uniform table reads
+    const FdtdSmallSource t = tab[i];
+    const unsigned dx = (unsigned)(x - t.x), dy = (unsigned)(y - t.y);
+    if (dx < 2u && dy < 2u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned dz = (unsigned)(zfirst + j - t.z);
+        if (dz < 2u) {
+          // openacc.cpp:194, evaluated left to right
+          const float r0 = 1.0e-2F * ((int)dx * t.px + (1 - (int)dx) * (1 - t.px)) *
+                           ((int)dy * t.py + (1 - (int)dy) * (1 - t.py)) * ((int)dz * t.pz + (1 - (int)dz) * (1 - t.pz)) *
+                           src_row[i] / t.mc;
+          o[j] += r0;
+        }
+      }
+    }
+  }
+  if (owned) *reinterpret_cast<float4 *>(a.u2 + c0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// Can the packed-rows kernel take this box?  Whole float4s in z, 16-byte aligned rows.
+static bool rows_eligible(const fdtd_geom *g, const float *m, const float *u0, const float *u1, const float *u2) {
+  const int ez = g->z_M - g->z_m + 1;
+  return ez >= 4 && ez % 4 == 0 && g->nzp % 4 == 0 && g->z_m % 4 == 0 &&
+         (((uintptr_t)m | (uintptr_t)u0 | (uintptr_t)u1 | (uintptr_t)u2) % 16) == 0 &&
+         (((long)g->nyp * g->nzp) % 4) == 0;
+}
+
+static void launch_rows(const StencilArgs &a, const FdtdSmallSource *table, const float *src_row, int nsrc, hipStream_t s) {
+  const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
+  // lanes per row: the narrowest packing that wastes fewest lanes (rows of 64 cells: 16, of 128: 32, ...)
+  auto padded = [ez](int lpr) { return (ez + 4 * lpr - 1) / (4 * lpr) * (4 * lpr); };
+  int lpr = 64;
+  if (padded(32) < padded(lpr)) lpr = 32;
+  if (padded(16) < padded(lpr)) lpr = 16;
+  lpr = env_int("FDTD_ROWS_LPR", lpr);
+  const int rows_per_wg = 4 * (64 / lpr);
+  const dim3 grid((ez + 4 * lpr - 1) / (4 * lpr), (ey + rows_per_wg - 1) / rows_per_wg, ex), block(256);
+  if (lpr == 16) hipLaunchKernelGGL(stencil_rows_kernel<16>, grid, block, 0, s, a, table, src_row, nsrc);
+  else if (lpr == 32) hipLaunchKernelGGL(stencil_rows_kernel<32>, grid, block, 0, s, a, table, src_row, nsrc);
+  else hipLaunchKernelGGL(stencil_rows_kernel<64>, grid, block, 0, s, a, table, src_row, nsrc);
+}
+
 static long g_small_steps = 0;
 
 // Fills the table of the sources p_src_m .. p_src_M (positions, weights, m at the position).
@@ -900,8 +989,11 @@ int fdtd_small_step(const struct fdtd_geom *g, const float *m, const float *u0, 
   if (ex <= 0 || ey <= 0 || ez <= 0) return 0;
   if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
   const StencilArgs a = make_args(g, m, u0, u1, u2);
-  hipLaunchKernelGGL(stencil_small_kernel, dim3((ez + 63) / 64, (ey + 3) / 4, ex), dim3(64, 4, 1), 0,
-                     (hipStream_t)stream, a, table, src_row, nsrc);
+  if (rows_eligible(g, m, u0, u1, u2) && env_int("FDTD_SMALL_ROWS", 1) != 0)
+    launch_rows(a, table, src_row, nsrc, (hipStream_t)stream);
+  else
+    hipLaunchKernelGGL(stencil_small_kernel, dim3((ez + 63) / 64, (ey + 3) / 4, ex), dim3(64, 4, 1), 0,
+                       (hipStream_t)stream, a, table, src_row, nsrc);
   __atomic_add_fetch(&g_small_steps, 1, __ATOMIC_RELAXED);
   return (int)hipGetLastError();
 }

@@ -310,6 +310,27 @@ def test_operator_staged_transfers(pkg, hiplib, chunk_kb, threads, monkeypatch):
         check_against_golden(name, c["u"], exact=True)
 
 
+@pytest.mark.parametrize("lpr", ["16", "32", "64"])
+def test_small_grid_packed_rows_kernel(pkg, hiplib, lpr, monkeypatch):
+    """The one-launch-per-step loop with every lane packing of its float4-per-lane kernel (a wave spanning
+    four rows of 64 cells, two of 128, one of 256) on every fixture case, and with the one-cell-per-thread
+    kernel it replaces on shapes it does not take; the bytes are the fixture's."""
+    monkeypatch.setenv("FDTD_ROWS_LPR", lpr)
+    monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "2000000000")   # every case through the small-grid loop
+    monkeypatch.setenv("FDTD_FUSE2", "0")
+    for name in cases.CASES:
+        c = cases.build(name, pkg)
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
+        assert rc == 0
+        check_against_golden(name, c["u"], exact=True)
+    monkeypatch.setenv("FDTD_SMALL_ROWS", "0")
+    for name in ("ricker_n32", "noncubic_aniso", "fused_z512_ricker8"):
+        c = cases.build(name, pkg)
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, c["m"], c["src"], c["coords"], c["u"], **c["kw"])
+        assert rc == 0
+        check_against_golden(name, c["u"], exact=True)
+
+
 @pytest.mark.parametrize("name", list(cases.CASES))
 def test_small_grid_time_loop(pkg, hiplib, name):
     """Default settings: grids below the marching kernel's threshold go through the one-launch-per-step
