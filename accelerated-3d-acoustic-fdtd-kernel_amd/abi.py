@@ -11,7 +11,7 @@ import numpy as np
 HALO = 4            # main.cpp:32, cuda.cu:55
 WARMUP_STEPS = 5    # openacc.cpp:5
 STATIC_SCRATCH_FLOATS = 4 << 20   # FDTD_STATIC_SCRATCH_FLOATS of fdtd_abi.h
-VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "march2": 5, "auto": -1}
+VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "march2": 5, "rows": 6, "auto": -1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -952,12 +952,10 @@ static bool rows_eligible(const fdtd_geom *g, const float *m, const float *u0, c
 
 static void launch_rows(const StencilArgs &a, const FdtdSmallSource *table, const float *src_row, int nsrc, hipStream_t s) {
   const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
-  // lanes per row: the narrowest packing that wastes fewest lanes (rows of 64 cells: 16, of 128: 32, ...)
-  auto padded = [ez](int lpr) { return (ez + 4 * lpr - 1) / (4 * lpr) * (4 * lpr); };
-  int lpr = 64;
-  if (padded(32) < padded(lpr)) lpr = 32;
-  if (padded(16) < padded(lpr)) lpr = 16;
-  lpr = env_int("FDTD_ROWS_LPR", lpr);
+  // Lanes per row.  Measured on MI355X (us per step, cubes): whole waves per row win from 144 cells on even
+  // with idle lanes (144^3: 11.5 with 64 lanes per row, 15.5 with 32, 19.7 with 16; 192^3: 19.9 / 24.6 / 28.2),
+  // half-waves at 128 and 96 (128^3: 9.1 / 6.9 / 8.8; 96^3: 7.1 / 5.7 / 6.0); below that a step is a launch.
+  const int lpr = env_int("FDTD_ROWS_LPR", ez > 128 ? 64 : (ez > 64 ? 32 : 16));
   const int rows_per_wg = 4 * (64 / lpr);
   const dim3 grid((ez + 4 * lpr - 1) / (4 * lpr), (ey + rows_per_wg - 1) / rows_per_wg, ex), block(256);
   if (lpr == 16) hipLaunchKernelGGL(stencil_rows_kernel<16>, grid, block, 0, s, a, table, src_row, nsrc);
@@ -1001,11 +999,14 @@ int fdtd_small_step(const struct fdtd_geom *g, const float *m, const float *u0, 
 // Statistics: sweep-and-scatter launches issued by this process so far.
 extern "C" long fdtd_hip_small_step_count(void) { return __atomic_load_n(&g_small_steps, __ATOMIC_RELAXED); }
 
-// Would the automatic choice run this box with the one-cell-per-thread kernel?
+// Does the automatic choice run this box with a one-shot kernel (packed rows, or one cell per thread)
+// rather than the marching kernel?  Below FDTD_MARCH_MIN_CELLS (16 M) cells: measured per step, packed
+// rows against marching: 192^3 19.9 against 30 us, 224^3 29.3 against 43.8, 240^3 41.7 against 45; at
+// 256^3 the marching kernel and the two-step sweep are ahead (55 against 51 us).
 bool fdtd_auto_is_naive(const struct fdtd_geom *g, const float *m, const float *u) {
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   const long cells = (long)ex * ey * ez;
-  return !(march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000) &&
+  return !(march_eligible(g, m, u) && cells >= env_int("FDTD_MARCH_MIN_CELLS", 16000000) &&
            ex >= env_int("FDTD_MARCH_MIN_PLANES", 8));
 }
 
@@ -1021,16 +1022,18 @@ int fdtd_stencil_levels(const struct fdtd_geom *g, const float *m, const float *
   if (variant == FDTD_VARIANT_MARCH2) variant = FDTD_VARIANT_AUTO;   // a single sweep cannot fuse
 
   if (variant == FDTD_VARIANT_AUTO) {
-    // Measured crossover on MI355X: below ~160^3 cells a sweep is a handful of microseconds
-    // and the one-cell-per-thread kernel (most workgroups, no prologue) wins; from 192^3 on
-    // the marching kernel does.
+    // Measured crossover on MI355X: below 16 M cells the grid is served from the caches and a one-shot
+    // kernel (no prologue, many workgroups) wins; from 256^3 on the marching kernel does.
     const long cells = (long)ex * ey * ez;
     // Ranges of fewer than 8 planes (the boundary planes of a slab) would spend more on priming
     // the register column than on the sweep: naive kernel as well.
-    variant = (eligible && cells >= env_int("FDTD_MARCH_MIN_CELLS", 6000000) &&
+    variant = (eligible && cells >= env_int("FDTD_MARCH_MIN_CELLS", 16000000) &&
                ex >= env_int("FDTD_MARCH_MIN_PLANES", 8))
-                  ? FDTD_VARIANT_MARCH : FDTD_VARIANT_NAIVE;
+                  ? FDTD_VARIANT_MARCH : FDTD_VARIANT_ROWS;
   }
+  // one-shot sweeps: float4 lanes with rows packed into waves where the shape allows, else one cell per thread
+  if (variant == FDTD_VARIANT_ROWS && (!rows_eligible(g, m, u0, u1, u2) || env_int("FDTD_SMALL_ROWS", 1) == 0))
+    variant = FDTD_VARIANT_NAIVE;
   if ((variant == FDTD_VARIANT_MARCH || variant == FDTD_VARIANT_VEC) && !eligible)
     variant = FDTD_VARIANT_NAIVE;
 
@@ -1040,6 +1043,11 @@ int fdtd_stencil_levels(const struct fdtd_geom *g, const float *m, const float *
       long blocks = (total + 255) / 256;
       if (blocks > 256L * 64) blocks = 256L * 64;  // grid-stride beyond 64 blocks per CU
       hipLaunchKernelGGL(stencil_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+      break;
+    }
+    case FDTD_VARIANT_ROWS: {
+      if (ex > 65535) return (int)hipErrorInvalidValue;
+      launch_rows(a, nullptr, nullptr, 0, s);
       break;
     }
     case FDTD_VARIANT_NAIVE: {

@@ -31,7 +31,7 @@ extern "C" void FDTD_SetRuntimeConfig(int use_tc, int t_fuse, int nfields) {
 }
 
 extern "C" const char *fdtd_hip_version(void) {
-  return "fdtd-hip gfx950 variants=flat,naive,march,tile3d,vec,march2 storage=f32,f16";
+  return "fdtd-hip gfx950 variants=flat,naive,march,tile3d,vec,march2,rows storage=f32,f16";
 }
 
 namespace {
@@ -648,6 +648,7 @@ static int optimized_variant() {
   if (!strcmp(v, "tile3d")) return FDTD_VARIANT_TILE3D;
   if (!strcmp(v, "vec")) return FDTD_VARIANT_VEC;
   if (!strcmp(v, "march2")) return FDTD_VARIANT_MARCH2;
+  if (!strcmp(v, "rows")) return FDTD_VARIANT_ROWS;
   return FDTD_VARIANT_AUTO;
 }
 

@@ -173,7 +173,8 @@ enum fdtd_variant {
   FDTD_VARIANT_TILE3D = 3,   /* 8x8x8 outputs from a 12x12x12 LDS tile              */
   FDTD_VARIANT_VEC = 4,      /* one-shot float4 lanes, cache-ordered launch          */
   FDTD_VARIANT_MARCH2 = 5,   /* two time steps per sweep (fdtd_hip_two_steps and the time loop only) */
-  FDTD_VARIANT_AUTO = -1     /* MARCH when the shape allows it, else NAIVE          */
+  FDTD_VARIANT_ROWS = 6,     /* one-shot float4 lanes, rows packed into waves (small and medium grids) */
+  FDTD_VARIANT_AUTO = -1     /* MARCH from 16 M cells on when the shape allows it, else ROWS, else NAIVE */
 };
 
 /* Geometry of one padded field set; passed by pointer. */

@@ -44,14 +44,14 @@ def test_operator_matches_golden(pkg, hiplib, op, name, monkeypatch):
     assert (prof.section0 > 0) == (n_steps > pkg.WARMUP_STEPS)  # warm-up steps are not timed
 
 
-@pytest.mark.parametrize("variant,ry,nw", [("flat", 0, 0), ("naive", 0, 0), ("vec", 0, 0), ("tile3d", 0, 0),
+@pytest.mark.parametrize("variant,ry,nw", [("flat", 0, 0), ("naive", 0, 0), ("vec", 0, 0), ("tile3d", 0, 0), ("rows", 0, 0),
                                            ("march", 2, 8), ("march", 4, 4), ("march", 2, 4), ("march", 1, 8), ("march", 1, 16)])
 @pytest.mark.parametrize("nt", ["0", "1"])
 def test_variants_and_tile_shapes(pkg, hiplib, variant, ry, nw, nt, monkeypatch):
     """Every stencil variant (and every rows-per-wave x waves-per-workgroup shape of the marching
     kernel, with and without non-temporal hints) gives the oracle's bits on shapes that exercise
     partial tiles in y and z, sub-ranges and full tiles."""
-    if nt == "0" and variant in ("flat", "naive", "tile3d"):
+    if nt == "0" and variant in ("flat", "naive", "tile3d", "rows"):
         pytest.skip("no non-temporal path in this variant")
     monkeypatch.setenv("FDTD_VARIANT", variant)
     monkeypatch.setenv("FDTD_NT", nt)
@@ -151,7 +151,7 @@ def test_impulse_mirror_symmetry(pkg, hiplib, op):
     half-way between the two central nodes of every axis feeds 8 equal corners, and the update
     (openacc.cpp:159-164) only ever adds the two members of a mirror pair to each other, so the
     field stays bit-for-bit mirror symmetric about the centre in x, y and z.  192^3 takes the
-    marching kernel in Kernel_CUDA_Optimized."""
+    packed-rows kernel in Kernel_CUDA_Optimized."""
     n, nt = 192, 24
     h = 0.125                                       # power of two: (c - o)/h is exact
     u, m, src, _ = pkg.standard_inputs(n, n, n, nt, 1)
