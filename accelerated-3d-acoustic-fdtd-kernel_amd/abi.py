@@ -142,6 +142,9 @@ def lib():
     L.fdtd_hip_fused_launch_count.restype = C.c_long
     L.fdtd_hip_two_steps_fuses.argtypes = [C.POINTER(Geom), C.c_int, C.c_int]
     L.fdtd_hip_two_steps_fuses.restype = C.c_int
+    L.fdtd_hip_two_steps_tiling.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_double)]
+    L.fdtd_hip_two_steps_tiling.restype = C.c_long
     L.fdtd_hip_small_step_count.argtypes = []
     L.fdtd_hip_small_step_count.restype = C.c_long
     L.fdtd_hip_one_step.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p]

@@ -163,22 +163,23 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // offsets move from the scalar to the per-lane part of the addresses, and the lanes 31 | 32 take their
 // z-neighbours from the edge loads like the lanes 0 and 63 do.  For cross-sections whose rows fill
 // multiples of 128 cells much better than multiples of 256 or 512 (384, 640).
-template <bool NT, int ZH, bool MASK, int LPR = 64>
-__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt, int wg_base) {
+//
+// march2_tile is the work of one workgroup: the tile(s) of y-tile index yt whose rows start at cell zb, on
+// x-chunk xc; cut_l / cut_r say whether another z-tile lies before / behind it (its outermost lanes then
+// serve the seam pass).  The kernels below map workgroups to tiles.
+typedef f32x4 (&BbufRef)[2][16][128];
+typedef f32x4 (&CringRef)[3][12][128];
+template <bool NT, int ZH, bool MASK, int LPR>
+__device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int zb, bool cut_l, bool cut_r, int yt,
+                                            int xc, BbufRef Bbuf, CringRef Cring) {
   static_assert(LPR == 64 || (LPR == 32 && ZH == 1), "half-wave tiles exist for rows of 128 cells only");
   constexpr int TILE_CELLS = ZH == 2 ? M2_ZCELLS : LPR * 4;   // z extent of a tile
   constexpr int TILE_F4 = TILE_CELLS / 4;                       // float4s per tile row
-  __shared__ f32x4 Bbuf[2][16][128];
-  __shared__ f32x4 Cring[3][12][128];
   const int lane = threadIdx.x & 63;
   const int zl = LPR == 64 ? lane : (lane & 31);     // position inside the row part
   const int half = LPR == 64 ? 0 : (lane >> 5);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = wave & 1, q = wave >> 1;
-  const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
-  // z-tile fastest: the tiles on either side of a z-cut read each other's edge cells and should share an L2
-  const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
-  const int zb = a.z_m + zt * TILE_CELLS;   // first cell of this z-tile
   const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (LPR == 64 ? (2 * yt + h) : (4 * yt + 2 * h + half)) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   const int hslot = q < 2 ? q : 12 + q;
   const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
   const int lz = ZH == 2 ? lc : zl;                     // float4 index inside the row of cells
-  const bool seam_lane = (lz == 0 && zt > 0) || (lz == TILE_F4 - 1 && zt < nzt - 1);   // next to a z-cut
+  const bool seam_lane = (lz == 0 && cut_l) || (lz == TILE_F4 - 1 && cut_r);   // next to a z-cut
   // MASK: float4s of this z-tile that are inside the row; lanes from nvalid on work on the address
   // of float4 `nvalid` (the four halo cells behind the row) and store nothing
   const int nvalid = MASK ? min(TILE_F4, (a.z_M + 1 - zb) >> 2) : TILE_F4;
@@ -495,6 +496,55 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
 #undef LD2
 }
 
+// Uniform tiling: every z-tile of the same kind; tile index = z-tile fastest (the tiles on either side of a
+// z-cut read each other's edge cells and should share an L2), then y-tile, then x-chunk.
+template <bool NT, int ZH, bool MASK, int LPR = 64>
+__global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt, int wg_base) {
+  __shared__ f32x4 Bbuf[2][16][128];
+  __shared__ f32x4 Cring[3][12][128];
+  constexpr int TILE_CELLS = ZH == 2 ? M2_ZCELLS : LPR * 4;
+  const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
+  march2_tile<NT, ZH, MASK, LPR>(a, xchunk, a.z_m + zt * TILE_CELLS, zt > 0, zt < nzt - 1, yt, xc, Bbuf, Cring);
+}
+
+// Mixed tiling: a row is covered by z-tiles of different kinds — tiles of 512 cells first, then one of 256,
+// then one of 128 (the last one masked if the row ends inside it) — so that rows of 384 = 256 + 128,
+// 640 = 512 + 128 or 768 = 512 + 256 cells fill every lane with a single cut or two.  Workgroups are
+// dealt in bands of 32 rows: a band is 4 workgroups per 512-cell tile (8 rows each), 2 per 256-cell tile
+// (two 8-row tiles each) and 1 per 128-cell tile (four), adjacent in tile index, so that everything that
+// touches the same rows shares an XCD's L2.
+struct MixedTiling {
+  int ntiles;            // z-tiles of a row
+  int kind[8];           // 0: 512 cells, 1: 256, 2: 128
+  int zoff[8];           // first cell of the z-tile, from z_m
+  int slots;             // workgroups per band
+  int nbands;
+};
+template <bool NT, bool MASK>
+__global__ __launch_bounds__(512) void stencil_march2_mixed_kernel(March2Args a, int xchunk, MixedTiling mt, int wg_base) {
+  __shared__ f32x4 Bbuf[2][16][128];
+  __shared__ f32x4 Cring[3][12][128];
+  const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int per_chunk = mt.slots * mt.nbands;
+  const int xc = t / per_chunk, r = t % per_chunk;
+  const int band = r / mt.slots;
+  int s = r % mt.slots, zi = 0;
+  for (; zi < mt.ntiles - 1; ++zi) {          // which z-tile the slot belongs to
+    const int n = 4 >> mt.kind[zi];
+    if (s < n) break;
+    s -= n;
+  }
+  const int kind = mt.kind[zi];
+  const int zb = a.z_m + mt.zoff[zi];
+  const bool cut_l = zi > 0, cut_r = zi < mt.ntiles - 1;
+  const int yt = band * (4 >> kind) + s;        // y-tile index in units of this kind's rows per workgroup
+  if (MASK && a.y_m + yt * (M2_ROWS << kind) > a.y_M) return;   // a workgroup wholly beyond the last row (last band)
+  if (kind == 0) march2_tile<NT, 2, MASK, 64>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+  else if (kind == 1) march2_tile<NT, 1, MASK, 64>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+  else march2_tile<NT, 1, MASK, 32>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+}
+
 // D on the four cells around every z-cut of the sweep above (cells cut-2 .. cut+1), from the C
 // level in memory once the sweep has completed it: same expression, same operand order.  One
 // thread per (row, cut, plane) computes the four cells as two pairs; the four cells start 8 bytes
@@ -506,14 +556,14 @@ struct SeamArgs {
   float *D;
   long sx;
   int sy, x_m, y_m, y_M, z_m;
-  int zstep;          // cells between cuts
+  int cut[8];         // first cell behind each cut, counted from z_m
   Coef2 k;
 };
 struct __attribute__((packed, aligned(4))) Quad { float v[4]; };
 __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
   const int y = a.y_m + (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (y > a.y_M) return;
-  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + ((int)blockIdx.y + 1) * a.zstep - 2;
+  const int x = a.x_m + (int)blockIdx.z, z = a.z_m + a.cut[blockIdx.y] - 2;
   const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
   auto ld = [](const float *p, long at) {
     const Quad q = *(const Quad *)(p + at);
@@ -639,12 +689,21 @@ int env_int2(const char *name, int fallback) {
 // its lanes and rows on padding is taken; a cross-section that does not fill its tiles exactly
 // runs the kernel's MASK variant.
 struct M2Tiling {
-  int zstep;     // cells per z-tile: 512 (one 8-row tile per workgroup), 256 (two), 128 (four)
+  int zstep;     // cells per z-tile: 512 (one 8-row tile per workgroup), 256 (two), 128 (four); 0: mixed
   bool mask;
   int tile_rows, nyt, nzt;
   double fill;   // cells of the cross-section / cells the tiles span
+  MixedTiling mixed;   // zstep == 0
+  long wgs;      // workgroups per plane
+  double cost;   // modelled ns per plane (see m2_tiling)
 };
 static M2Tiling m2_tiling(int ey, int ez) {
+  // Cost model, from measurements on MI355X: a workgroup with full tiles of 512 or 256 cells takes 4.4 us
+  // per plane-iteration, 256 workgroups at a time, i.e. 17.2 ns per workgroup and plane; one whose rows end
+  // inside the tile less (4.0 us at three quarters: 0.7 + 0.3 x fill); one with four tiles of 128 cells 5.1
+  // to 5.6 us (its row pieces are 512 bytes long); every z-cut adds a seam pass of 0.14 ns per row and plane.
+  constexpr double WG_NS = 17.2, NARROW = 1.3, SEAM_NS = 0.14;
+  auto partial = [](int cells, int tile) { return 0.7 + 0.3 * (double)cells / tile; };
   auto make = [&](int zstep) {
     M2Tiling t;
     t.zstep = zstep;
@@ -653,13 +712,54 @@ static M2Tiling m2_tiling(int ey, int ez) {
     t.nzt = (ez + t.zstep - 1) / t.zstep;
     t.mask = (ez % t.zstep) != 0 || (ey % t.tile_rows) != 0;
     t.fill = (double)ey * ez / ((double)t.nyt * t.tile_rows * t.nzt * t.zstep);
+    t.wgs = (long)t.nyt * t.nzt;
+    const int last = ez - (t.nzt - 1) * zstep;   // cells of a row in its last z-tile
+    t.cost = t.nyt * WG_NS * (zstep == 128 ? NARROW : 1.0) * ((t.nzt - 1) + partial(last, zstep)) +
+             (t.nzt - 1) * SEAM_NS * ey;
+    t.mixed.ntiles = 0;
+    return t;
+  };
+  // rows covered by tiles of 512 cells, then one of 256, then one of 128 (masked if the row ends inside it)
+  auto make_mixed = [&]() {
+    M2Tiling t = make(M2_ZCELLS);
+    MixedTiling &mt = t.mixed;
+    mt.ntiles = 0; mt.slots = 0;
+    int z = 0, narrow_slots = 0;
+    double wg_cost = 0.0;
+    auto add = [&](int kind) {
+      const int width = M2_ZCELLS >> kind, cells = ez - z < width ? ez - z : width;
+      mt.kind[mt.ntiles] = kind; mt.zoff[mt.ntiles] = z; ++mt.ntiles;
+      mt.slots += 4 >> kind;
+      narrow_slots += kind == 2;
+      wg_cost += (4 >> kind) * (kind == 2 ? NARROW : 1.0) * partial(cells, width);
+      z += width;
+    };
+    while (ez - z >= M2_ZCELLS && mt.ntiles < 8) add(0);
+    if (ez - z >= 256 + 128 + 4 && mt.ntiles < 8) add(0);        // more than 256 + 128 left: one masked tile of 512
+    else {
+      if (ez - z > 128 && mt.ntiles < 8) add(1);                 // 132 .. 384 left: a tile of 256 (masked up to 252)
+      if (ez - z > 0 && mt.ntiles < 8) add(2);                   // up to 128 left
+    }
+    if (z < ez) { t.mixed.ntiles = 0; return t; }                // more than 8 z-tiles: not a case for this tiling
+    mt.nbands = (ey + 31) / 32;
+    t.zstep = 0;
+    t.nzt = mt.ntiles;
+    t.nyt = mt.nbands;
+    t.tile_rows = 32;
+    t.mask = z != ez || ey % 32 != 0;
+    t.fill = (double)ey * ez / ((double)mt.nbands * 32 * z);
+    t.wgs = (long)mt.nbands * mt.slots;
+    t.cost = mt.nbands * wg_cost * WG_NS + (mt.ntiles - 1) * SEAM_NS * ey;
+    // The workgroups with tiles of 128 cells are the slowest of a launch; where they are more than a quarter
+    // of it the others wait for them (384 = 256 + 128: 313 against 329 Gcells/s with masked tiles of 512).
+    if (4 * narrow_slots > mt.slots) t.cost *= 1.25;
     return t;
   };
   const int forced = env_int2("FDTD_FUSE2_TILE", 0);
   if (forced == 512 || forced == 256 || forced == 128) return make(forced);
   // Tiles of 512 or 256 cells: whichever fills better, the wider one on ties (fewer z-cuts, each of which
-  // costs a seam pass over four cells per row and plane).  Tiles of 128 cells are taken on request only
-  // (FDTD_FUSE2_TILE=128, or FDTD_FUSE2_NARROW_GAIN=g: when they fill better by g percent): measured on
+  // costs a seam pass over four cells per row and plane).  Tiles of 128 cells throughout are taken on request
+  // only (FDTD_FUSE2_TILE=128, or FDTD_FUSE2_NARROW_GAIN=g: when they fill better by g percent): measured on
   // MI355X their sweep is about 10 % slower per cell than the 256-cell one and every additional cut costs
   // 0.14 us per 1000 rows-times-planes, which eats the better fill — 384^3: 294 against 330 Gcells/s with
   // masked 512-cell tiles, 640^3: 332 against 322, 520^3: 273 against 283, 768^3: 338 against 408.
@@ -672,6 +772,19 @@ static M2Tiling m2_tiling(int ey, int ez) {
   if (narrow_gain > 0) {
     const M2Tiling t = make(M2_ZCELLS / 4);
     if (t.fill > best.fill * (1.0 + narrow_gain / 100.0)) best = t;
+  }
+  // The mixed tiling where the model says it pays by at least 3 % (FDTD_FUSE2_MIXED=0 never, =2 whenever it
+  // applies): one cut where the uniform tilings need two or waste a quarter of their lanes.  Measured
+  // (Gcells/s, mixed against the better uniform tiling): 520^3 322 / 282, 640^3 372 / 322, 768^3 422 / 407,
+  // 896^3 375 / 378, 384^3 313 / 329.
+  const int mixed_mode = env_int2("FDTD_FUSE2_MIXED", 1);
+  if (mixed_mode != 0 && forced == 0) {
+    const M2Tiling t = make_mixed();
+    if (t.mixed.ntiles > 1 && t.zstep == 0) {
+      bool uniform = true;   // every tile of one kind and none masked in z: the uniform kernels do that
+      for (int i = 1; i < t.mixed.ntiles; ++i) uniform = uniform && t.mixed.kind[i] == t.mixed.kind[0];
+      if (!(uniform) && (mixed_mode == 2 || t.cost < 0.97 * best.cost)) best = t;
+    }
   }
   return best;
 }
@@ -762,8 +875,8 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // 1024^3 at 372 instead of 437 Gcells/s).
   const int ez = g->z_M - g->z_m + 1;
   const M2Tiling tl = m2_tiling(ey, ez);
-  const int zstep = tl.zstep, nyt = tl.nyt, nzt = tl.nzt;
-  const int ntile = nyt * nzt;
+  const int zstep = tl.zstep, nyt = tl.nyt, nzt = tl.nzt;   // zstep 0: mixed tiling (tl.mixed)
+  const long ntile = tl.wgs;                                // workgroups per x-chunk
   // a workgroup addresses its xchunk + 9 planes with 32-bit offsets from its first plane
   const long plane_bytes = (long)g->nyp * g->nzp * 4;
   const long addressable = ((1L << 31) - 1) / plane_bytes - 9;
@@ -918,7 +1031,10 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     else                                                                                                     \
       hipLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_, LPR_>), grid, block, 0, s, a, xchunk, nyt, nzt, b); \
   } while (0)
-      if (zstep == M2_ZCELLS) {
+      if (zstep == 0) {
+        if (tl.mask) hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, true>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+        else hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, false>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+      } else if (zstep == M2_ZCELLS) {
         if (tl.mask) { if (nt) M2_LAUNCH(true, 2, true, 64); else M2_LAUNCH(false, 2, true, 64); }
         else { if (nt) M2_LAUNCH(true, 2, false, 64); else M2_LAUNCH(false, 2, false, 64); }
       } else if (zstep == M2_ZCELLS / 2) {
@@ -943,13 +1059,16 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2;
     sa.sx = a.sx; sa.sy = a.sy; sa.x_m = g->x_m; sa.y_m = g->y_m; sa.y_M = g->y_M; sa.z_m = g->z_m;
     sa.k = a.k;
-    sa.zstep = zstep;
-    // grid.z is limited to 65535 planes
-    for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
-      sa.x_m = x0;
-      const int planes = g->x_M - x0 + 1 < 65535 ? g->x_M - x0 + 1 : 65535;
-      hipLaunchKernelGGL(seam_kernel, dim3((unsigned)((ey + 255) / 256), (unsigned)(nzt - 1), (unsigned)planes),
-                         dim3(256), 0, s, sa);
+    // eight cuts per launch; grid.z is limited to 65535 planes
+    for (int c0 = 1; c0 < nzt; c0 += 8) {
+      const int ncut = nzt - c0 < 8 ? nzt - c0 : 8;
+      for (int i = 0; i < ncut; ++i) sa.cut[i] = zstep ? (c0 + i) * zstep : tl.mixed.zoff[c0 + i];
+      for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
+        sa.x_m = x0;
+        const int planes = g->x_M - x0 + 1 < 65535 ? g->x_M - x0 + 1 : 65535;
+        hipLaunchKernelGGL(seam_kernel, dim3((unsigned)((ey + 255) / 256), (unsigned)ncut, (unsigned)planes), dim3(256),
+                           0, s, sa);
+      }
     }
   }
   if (many) {
@@ -1083,6 +1202,18 @@ extern "C" int fdtd_hip_two_steps_fuses(const struct fdtd_geom *g, int nsrc, int
   if (env_int2("FDTD_FUSE2", 1) == 0) return 0;
   if (!fdtd_march2_eligible(g, nullptr, nullptr, nullptr, nullptr, nullptr, nsrc)) return 0;
   return (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g)) ? 1 : 0;
+}
+
+// How the two-step sweep tiles a cross-section of ey rows of ez cells: *zstep = 512, 256 or 128 (uniform
+// z-tiles) or 0 (mixed: tiles of 512, then 256, then 128 cells), *ncuts = z-cuts per row (each costs a seam
+// pass), *fill = cells / cells spanned by the tiles.  Returns the workgroups per plane.
+extern "C" long fdtd_hip_two_steps_tiling(int ey, int ez, int *zstep, int *ncuts, double *fill) {
+  if (ey < 1 || ez < 4) return 0;
+  const M2Tiling t = m2_tiling(ey, ez);
+  if (zstep) *zstep = t.zstep;
+  if (ncuts) *ncuts = t.nzt - 1;
+  if (fill) *fill = t.fill;
+  return t.wgs;
 }
 
 // Number of two-step sweep launches issued by this process so far (lets a caller or a test see

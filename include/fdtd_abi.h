@@ -255,6 +255,11 @@ int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *s
  * 16-byte aligned)?  1 or 0; variant as for fdtd_hip_two_steps. */
 int fdtd_hip_two_steps_fuses(const struct fdtd_geom *g, int nsrc, int variant);
 
+/* How the two-step sweep tiles a cross-section of ey rows of ez cells: *zstep = 512, 256 or 128 (uniform
+ * z-tiles) or 0 (mixed: tiles of 512, then one of 256, then one of 128 cells), *ncuts = z-cuts per row,
+ * *fill = cells / cells the tiles span.  Returns the workgroups per plane (0 for an empty cross-section). */
+long fdtd_hip_two_steps_tiling(int ey, int ez, int *zstep, int *ncuts, double *fill);
+
 /* Statistics: how many two-step sweep kernels this process has launched so far (tells a
  * caller whether its calls were fused or ran as two sweeps). */
 long fdtd_hip_fused_launch_count(void);

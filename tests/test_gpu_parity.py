@@ -237,8 +237,11 @@ def test_device_resident_time_loop_matches_operator(pkg, hiplib):
                                                 ((20, 24, 4), 1, "march2"), ((24, 5, 512), 2, "march2"),
                                                 ((24, 1, 256), 1, "march2"), ((30, 3, 520), 2, "march2"),
                                                 ((24, 2, 1028), 2, "march2"), ((30, 20, 516), 12, "march2"),
-                                                ((24, 5, 260), 10, "march2")])
-@pytest.mark.parametrize("tile", ["", "128", "256"])
+                                                ((24, 5, 260), 10, "march2"),
+                                                ((24, 32, 384), 2, "march2"), ((24, 64, 640), 3, "march2"),
+                                                ((24, 32, 768), 2, "march2"), ((20, 40, 896), 2, "march2"),
+                                                ((24, 20, 388), 2, "march2"), ((24, 70, 1156), 12, "march2")])
+@pytest.mark.parametrize("tile", ["", "128", "256", "mixed"])
 def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, variant, tile, monkeypatch):
     """fdtd_hip_two_steps, fused sweep against the two single sweeps it stands for (those are
     oracle-checked by the other tests), bit for bit, on random fields with different halos per level:
@@ -246,13 +249,18 @@ def test_two_steps_fused_equals_two_single_steps(pkg, hiplib, shape, nsrc, varia
     sources, an x range long enough to be cut into two launches (520 planes at 64 y-tiles), and rows
     of 1024, 1536 and 768 cells (two and three z-tiles of 512, three of 256; the cells around the cuts
     are redone by the seam pass); a full cross-section of 256 tiles in three launches; and cross-sections
+    (384 = 256 + 128, 640 = 512 + 128, 768 = 512 + 256, 896 = 512 + 256 + 128, 388 and 1156 with a masked last tile: the
+    mixed tiling, which the automatic choice takes for them), and cross-sections
     that do not fill their tiles (rows ending inside a z-tile, inside the first half of one, eight cells into
     one; fewer than 8 or 16 rows in the last y-tile, or in the whole box; rows that end on the first float4 of a wave, in the
     second wave of a 512-cell tile, in a z-tile of its own, in both tilings; rows of 4 cells), which run
     the masked variant of the kernel."""
     import torch
     monkeypatch.setenv("FDTD_FUSE2_MIN_CELLS", "0")   # the automatic choice would leave the small shapes alone
-    if tile:                                          # every shape through tiles of 128 / 256 cells as well
+    if tile == "mixed":                               # rows cut into tiles of 512, then 256, then 128 cells
+        monkeypatch.setenv("FDTD_FUSE2_MIXED", "2")
+        monkeypatch.setenv("FDTD_FUSE2_MIN_FILL", "0")
+    elif tile:                                        # every shape through tiles of 128 / 256 cells as well
         monkeypatch.setenv("FDTD_FUSE2_TILE", tile)
         monkeypatch.setenv("FDTD_FUSE2_MIN_FILL", "0")
     nx, ny, nz = shape
@@ -385,14 +393,16 @@ def test_two_steps_rejects_overlapping_levels(pkg, hiplib):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
-@pytest.mark.parametrize("tile", ["", "128"])
+@pytest.mark.parametrize("tile", ["", "128", "mixed"])
 def test_forced_fused_sweep_on_every_case(pkg, hiplib, name, tile, monkeypatch):
     """FDTD_VARIANT=march2: every fixture case whose box has rows of whole float4s goes
     through the two-step sweep (masked tiles for all but the fused_z* shapes; with 27 and 30 sources the
     scatter and repair passes behind the sweep), the others through the ordinary loop; the bytes are the
     fixture's either way."""
     monkeypatch.setenv("FDTD_VARIANT", "march2")
-    if tile:
+    if tile == "mixed":
+        monkeypatch.setenv("FDTD_FUSE2_MIXED", "2")
+    elif tile:
         monkeypatch.setenv("FDTD_FUSE2_TILE", tile)
     c = cases.build(name, pkg)
     before = hiplib.fdtd_hip_fused_launch_count()
@@ -540,7 +550,9 @@ def test_fp16_storage_512_cubed(pkg, hiplib):
 @pytest.mark.parametrize("shape,nsrc,what", [((32, 512, 1024), 3, "two z-tiles of 512 cells: seam pass"),
                                              ((36, 500, 1000), 2, "masked tiles in y and z"),
                                              ((40, 640, 640), 12, "more than 8 sources: scatter and repair passes"),
-                                             ((48, 768, 768), 2, "three z-tiles of 256 cells")])
+                                             ((48, 768, 768), 2, "tiles of 512 and 256 cells"),
+                                             ((44, 640, 640), 3, "tiles of 512 and 128 cells"),
+                                             ((112, 384, 384), 2, "tiles of 256 and 128 cells")])
 def test_large_fused_shapes_against_oracle(pkg, hiplib, shape, nsrc, what):
     """The two-step sweep on cross-sections of the size the benchmarks use (16 M cells and more), compared with
     the CPU oracle directly rather than with another HIP kernel: random fields with different halos per level,
