@@ -187,7 +187,7 @@ extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_ve
   if ((rc = buf.alloc((void **)&d_u, 3 * vol * sizeof(float)))) return rc;
   if ((rc = buf.alloc((void **)&d_m, vol * sizeof(float)))) return rc;
   if ((rc = buf.alloc((void **)&d_damp, vol * sizeof(float)))) return rc;
-  StagedCopier copier;
+  StagedCopier &copier = staged_copier_for_current_device();
   if ((rc = copier.to_device(d_u, u_vec->data, 3 * vol * sizeof(float)))) return rc;
   if ((rc = copier.to_device(d_m, m_vec->data, vol * sizeof(float)))) return rc;
   if ((rc = copier.to_device(d_damp, damp_vec->data, vol * sizeof(float)))) return rc;

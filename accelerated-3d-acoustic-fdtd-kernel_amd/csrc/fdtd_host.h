@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -126,3 +127,31 @@ class StagedCopier {
     return 0;
   }
 };
+
+// The copier of the current device: its pinned bounce buffers, stream and events are made once per device
+// and kept for the life of the process (48 MB of page-locked memory per device in use; never freed, so that
+// nothing of it is torn down after the HIP runtime at exit).  Operator calls are sequential (main.cpp:394);
+// callers serialise their use of it.
+inline StagedCopier &staged_copier_for_current_device() {
+  static StagedCopier *per_device[64] = {};
+  static std::string settings[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  // the switches a copier reads when it is made; a copier made under other settings is replaced
+  std::string now;
+  for (const char *name : {"FDTD_STAGING", "FDTD_STAGE_THREADS", "FDTD_STAGE_CHUNK_KB", "FDTD_STAGE_MIN_KB"}) {
+    const char *v = getenv(name);
+    now += v ? v : "";
+    now += '|';
+  }
+  if (per_device[dev] && settings[dev] != now) {
+    delete per_device[dev];
+    per_device[dev] = nullptr;
+  }
+  if (!per_device[dev]) {
+    per_device[dev] = new StagedCopier();
+    settings[dev] = now;
+  }
+  return *per_device[dev];
+}

@@ -189,6 +189,7 @@ struct StoreF32 {
   static constexpr int CELLS = 4;
   static constexpr int ELEM = 4;
   typedef f32x4 raw_t;
+  typedef f32x4 mem_t;   // a lane's 4 cells start 16 bytes into a 16-byte aligned row
   typedef f32x2 edge_t;  // 2 cells
   static __device__ __forceinline__ void unpack(raw_t v, float (&f)[CELLS]) {
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -213,6 +214,10 @@ struct StoreF16 {
   static constexpr int CELLS = 8;
   static constexpr int ELEM = 2;
   typedef u32x4 raw_t;      // 8 packed binary16
+  // In memory a lane's 8 cells start (z + 4) * 2 bytes into the row with z a multiple of 8: 8 bytes off a
+  // 16-byte boundary.  The 16-byte accesses are therefore declared 8-byte aligned (gfx9 global accesses need
+  // dword alignment only; the instruction is the same global_load_dwordx4).
+  typedef u32x4 mem_t __attribute__((aligned(8)));
   typedef unsigned edge_t;  // 2 packed binary16
   static __device__ __forceinline__ float lo(unsigned w) {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
@@ -251,15 +256,16 @@ struct MarchSet {
   typename ST::raw_t halo;      // one row outside the workgroup tile, plane +2 like col (loader waves)
 };
 
-template <bool NT, typename T>
+// T: the register type; M: the same vector as it lies in memory (possibly with a smaller alignment)
+template <bool NT, typename T, typename M = T>
 __device__ __forceinline__ T ld_raw(const char *p) {
-  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
-  else return *reinterpret_cast<const T *>(p);
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const M *>(p));
+  else return *reinterpret_cast<const M *>(p);
 }
-template <bool NT, typename T>
+template <bool NT, typename T, typename M = T>
 __device__ __forceinline__ void st_raw(char *p, T v) {
-  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
-  else *reinterpret_cast<T *>(p) = v;
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<M *>(p));
+  else *reinterpret_cast<M *>(p) = v;
 }
 
 // Level pointers are passed as bytes so that one kernel serves both storage types.
@@ -340,8 +346,8 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
   const char *pm = ma.m + (long)(x_begin + FDTD_HALO) * sxm;
   char *pu2 = ma.u2 + (long)(x_begin + FDTD_HALO) * sxe;
 
-#define LDU(p, off) ld_raw<false, raw_t>((p) + (size_t)(off) * ST::ELEM)
-#define LDS_(p, off) ld_raw<NT, raw_t>((p) + (size_t)(off) * ST::ELEM)
+#define LDU(p, off) ld_raw<false, raw_t, typename ST::mem_t>((p) + (size_t)(off) * ST::ELEM)
+#define LDS_(p, off) ld_raw<NT, raw_t, typename ST::mem_t>((p) + (size_t)(off) * ST::ELEM)
 #define LDE(p, off) ld_raw<false, edge_t>((p) + (size_t)(off) * ST::ELEM)
 #define LDM(p, off, j) ld_raw<NT, f32x4>((p) + (size_t)(off) * 4 + 16 * (j))
 
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(NW * 64) void stencil_march_lds_kernel(MarchArgs ma
         o[i] = update_cell(k, c[i], xm2[i], xm1[i], xp1[i], xp2[i], ym2[i], ym1[i], yp1[i], yp2[i],
                            zz[i], zz[i + 1], zz[i + 3], zz[i + 4], up[i], mc[i]);
       if (FULL || (owned && y0 + r <= a.y_M))
-        st_raw<NT, raw_t>(pu2 + (size_t)voff[r] * ST::ELEM, ST::pack(o));
+        st_raw<NT, raw_t, typename ST::mem_t>(pu2 + (size_t)voff[r] * ST::ELEM, ST::pack(o));
     }
 
     // ---- advance: shift the four older planes, step the plane pointers ----

@@ -397,7 +397,7 @@ extern "C" int Kernel_HIP_MultiGPU(FDTD_OPERATOR_ARGS) {
     FDTD_HIP_CHECK(hipStreamCreateWithFlags(&v.copy, hipStreamNonBlocking));
     for (hipEvent_t *e : {&v.ev_interior, &v.ev_boundary, &v.ev_ready, &v.ev_shell, &v.ev_push_left, &v.ev_push_right})
       FDTD_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    StagedCopier copier;
+    StagedCopier &copier = staged_copier_for_current_device();
     for (int l = 0; l < 3; ++l) {
       rc = copier.to_device(v.lv[l], hu + (size_t)l * vol + (size_t)v.off * plane, lvol * sizeof(float));
       if (rc) return rc;
@@ -465,7 +465,7 @@ extern "C" int Kernel_HIP_MultiGPU(FDTD_OPERATOR_ARGS) {
     FDTD_HIP_CHECK(hipStreamSynchronize(v.edge));
     // owned planes, plus the physical padding on the first and the last slab
     const int lo = v.left < 0 ? 0 : FDTD_HALO, hi = v.right < 0 ? v.nx + 2 * FDTD_HALO : v.nx + FDTD_HALO;
-    StagedCopier copier;
+    StagedCopier &copier = staged_copier_for_current_device();
     for (int l = 0; l < 3; ++l) {
       rc = copier.to_host(hu_out + (size_t)l * vol + (size_t)(v.off + lo) * plane, v.lv[l] + (size_t)lo * plane,
                           (size_t)(hi - lo) * plane * sizeof(float));

@@ -536,7 +536,7 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
       if (slot >= 0) g_resident.erase(g_resident.begin() + slot);
     }
   } cleanup{&res, slot};
-  StagedCopier copier;
+  StagedCopier &copier = staged_copier_for_current_device();
   if (!reuse) {
     FDTD_HIP_CHECK(hipMalloc((void **)&d.u, 3 * vol * sizeof(float)));
     FDTD_HIP_CHECK(hipMalloc((void **)&d.m, vol * sizeof(float)));

@@ -354,10 +354,17 @@ int fdtd_hip_copy_shell(const struct fdtd_geom *g, float *dst_level, const float
 
 /* The whole time loop on device-resident fields: steps time_m..time_M, ring
  * indexing and section timers exactly as the operators do (timers may be NULL, in
- * which case nothing is timed and no host synchronisation happens before return
- * other than the final stream synchronise).  This is the body of every Kernel_*
- * operator between its host-to-device and device-to-host copies
- * (cuda.cu:232-314). */
+ * which case nothing is timed).  This is the body of every Kernel_* operator between
+ * its host-to-device and device-to-host copies (cuda.cu:232-314).  The call returns
+ * after a final stream synchronise.  Beyond that: where it takes the two-step sweep
+ * (boxes of 16 M cells and more) it allocates a fourth level buffer and a flag for the
+ * duration of the call, reads the source positions back once (one small device-to-host
+ * copy and a stream synchronise before the first step) and ends with up to four
+ * level copies that put the three newest levels into their ring slots; where it takes
+ * the one-launch-per-step loop (smaller boxes) it allocates a table of the sources and
+ * reads the positions back the same way.  Callers that cannot have allocations or
+ * synchronisations inside their loop drive fdtd_hip_two_steps / fdtd_hip_one_step
+ * (or the sweep and scatter calls) themselves. */
 int fdtd_hip_time_loop(const struct fdtd_geom *g, const float *m, const float *src,
                        const float *src_coords, float *u, int p_src_m, int p_src_M,
                        int src_stride, int coord_stride, int time_m, int time_M,
