@@ -317,6 +317,14 @@ extern "C" int Kernel_HIP_MultiGPU(FDTD_OPERATOR_ARGS) {
     return Kernel_CUDA_Optimized(m_vec, src_vec, src_coords_vec, u_vec, x_M, x_m, y_M, y_m, z_M, z_m, dt, h_x, h_y, h_z,
                                  o_x, o_y, o_z, p_src_M, p_src_m, time_M, time_m, devices[0], devicerm, timers);
 
+  // the calling thread's current device is put back on every way out
+  struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { (void)hipGetDevice(&dev); }
+    ~DeviceGuard() {
+      if (dev >= 0) (void)hipSetDevice(dev);
+    }
+  } device_guard;
   const float *hu = (const float *)u_vec->data, *hm = (const float *)m_vec->data;
   // shells follow the ring unless the three levels start with identical shells and no source corner can
   // reach the halo layer (positions as openacc.cpp:185-187 computes them)

@@ -552,7 +552,8 @@ def test_fp16_storage_512_cubed(pkg, hiplib):
                                              ((40, 640, 640), 12, "more than 8 sources: scatter and repair passes"),
                                              ((48, 768, 768), 2, "tiles of 512 and 256 cells"),
                                              ((44, 640, 640), 3, "tiles of 512 and 128 cells"),
-                                             ((112, 384, 384), 2, "tiles of 256 and 128 cells")])
+                                             ((112, 384, 384), 2, "tiles of 256 and 128 cells"),
+                                             ((34, 2048, 2048), 2, "the cross-section of the 2048^3 configuration: four z-tiles of 512")])
 def test_large_fused_shapes_against_oracle(pkg, hiplib, shape, nsrc, what):
     """The two-step sweep on cross-sections of the size the benchmarks use (16 M cells and more), compared with
     the CPU oracle directly rather than with another HIP kernel: random fields with different halos per level,
