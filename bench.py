@@ -415,6 +415,19 @@ def main():
                 else:   # experiment: no events at all, the launch period stands in for the kernel time
                     kernel_ms_reps.append(elapsed / max(1, n_pairs) * 1e3)
                 newest = P[cur]
+            elif args.variant == "auto" and not h16 and os.environ.get("FDTD_BENCH_TIME_LOOP", "1") != "0":
+                # Boxes the library does not fuse (below 16 M cells): its own time loop, which runs them with one
+                # launch per step (sweep and scatter in one kernel).  No per-kernel events: the time per step,
+                # launch gap included, stands in for the kernel time.
+                tl_args = (C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), u_d.data_ptr(), 0, 0, 1, 3)
+                assert L.fdtd_hip_time_loop(*tl_args, 0, W - 1, variant, sh, None) == 0
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+                assert L.fdtd_hip_time_loop(*tl_args, W, total_steps - 1, variant, sh, None) == 0
+                torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t_start
+                kernel_ms_reps.append(elapsed / K * 1e3)
+                newest = u_d[total_steps % 3]
             else:
                 for t in range(W):
                     assert stencil(t % 3, (t + 2) % 3, (t + 1) % 3) == 0
