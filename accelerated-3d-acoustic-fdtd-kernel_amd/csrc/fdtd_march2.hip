@@ -25,15 +25,15 @@
 // counted waits).  Memory is addressed with buffer instructions: descriptor (scalar) + plane
 // offset (scalar) + one loop-invariant 32-bit lane offset per row.
 //
-// Shapes: tiles of 8 rows x 512 cells, or of 16 rows x 256 cells (the workgroup then carries two
-// 8-row tiles of 256-cell rows, one per wave parity), whichever the cross-section fills better; a
-// cross-section that does not fill its tiles runs the MASK instantiation.  Rows must be whole
-// float4s; anything else is run as two single sweeps by fdtd_hip_two_steps.  Up to 8 sources are scattered by the sweep itself, more by passes behind
-// it (repair_kernel).
-// Longer rows are cut into z-tiles of 512 (or 256) cells.  A tile cannot know its neighbour's C
-// beyond the cut in time, so the four D cells around every cut (two on either side) come out wrong
-// and are recomputed by seam_kernel after the sweep, from the C level in memory; the second scatter
-// then runs as a launch of its own after that.
+// Shapes: a workgroup carries one tile of 8 rows x 512 cells, two of 8 x 256 (one per wave parity) or four
+// of 8 x 128 (one per half-wave).  A row is covered by z-tiles of one kind, or by a mix (tiles of 512 cells,
+// then one of 256, then one of 128: stencil_march2_mixed_kernel), whichever the cost model of m2_tiling
+// prefers; a cross-section that does not fill its tiles runs the MASK instantiations.  Rows must be whole
+// float4s; anything else is run as two single sweeps by fdtd_hip_two_steps.  Up to 8 sources are scattered
+// by the sweep itself, more by passes behind it (repair_kernel).
+// Where a row has more than one z-tile, a tile cannot know its neighbour's C beyond the cut in time, so
+// the four D cells around every cut (two on either side) come out wrong and are recomputed by seam_kernel
+// after the sweep, from the C level in memory; the second scatter then runs as a launch of its own.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdio.h>
@@ -684,10 +684,9 @@ int env_int2(const char *name, int fallback) {
 
 }  // namespace
 
-// How the (y, z) cross-section of a box is cut into tiles: rows of 512 cells in tiles of 8 rows
-// ("wide"), or rows of 256 cells with two 8-row tiles per workgroup.  Whichever wastes less of
-// its lanes and rows on padding is taken; a cross-section that does not fill its tiles exactly
-// runs the kernel's MASK variant.
+// How the (y, z) cross-section of a box is cut into tiles: uniform z-tiles of 512, 256 or 128 cells
+// (8, 16 or 32 rows per workgroup), or the mixed tiling; a cross-section that does not fill its tiles
+// exactly runs the MASK variants.
 struct M2Tiling {
   int zstep;     // cells per z-tile: 512 (one 8-row tile per workgroup), 256 (two), 128 (four); 0: mixed
   bool mask;

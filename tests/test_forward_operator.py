@@ -1,4 +1,4 @@
-"""Kernel_HIP_Forward: the update with an absorbing sponge, the source scatter and receivers (SURVEY row f4).
+"""Kernel_HIP_Forward: the update with an absorbing sponge, the source scatter and receivers.
 
 PARITY UNPINNED: the reference has no sponge and no receivers, so nothing of its own can be compared.  What is
 checked: the HIP operator against the C restatement of the same form bit for bit; that the form degenerates to

@@ -1,4 +1,4 @@
-"""Space orders 6 and 8 (SURVEY row f2; the reference driver's STENCIL_ORDER, main.cpp:27-32).
+"""Space orders 6 and 8 (the reference driver's STENCIL_ORDER, main.cpp:27-32).
 
 PARITY UNPINNED for orders 6 and 8: no reference kernel implements them (openacc.cpp:102-107 hard-codes
 order 4), so there is nothing of the reference's to compare with.  What is pinned: the generic
