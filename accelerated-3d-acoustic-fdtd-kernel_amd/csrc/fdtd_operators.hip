@@ -111,21 +111,64 @@ struct SectionTimer {
 // halo layer.  At the end box and shell of the three newest levels go back to the slots the
 // ring leaves them in; padding further out is never read or written and stays as the caller
 // gave it.
+namespace {
+constexpr int kMaxSpareDevices = 64;
+struct SpareLevel {
+  float *level = nullptr;
+  size_t floats = 0;
+  bool in_use = false;
+};
+SpareLevel g_spare[kMaxSpareDevices];
+std::mutex g_spare_mutex;
+}  // namespace
+
 static int time_loop_fused(const struct fdtd_geom *g, const float *m, const float *src,
                            const float *src_coords, float *u, int p_src_m, int p_src_M, int src_stride,
                            int coord_stride, int time_m, int time_M, int variant, hipStream_t s,
                            struct profiler *timers, bool has_src) {
   const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
+  // The fourth level buffer and the flag: kept per device between calls (one allocation of a level is a
+  // millisecond at 512^3), handed to one time loop at a time; a second loop running on the same device at
+  // the same time allocates its own.  fdtd_hip_release_device_copies frees the kept one.
   struct Owned {
     float *level = nullptr;
     int *flag = nullptr;
+    int dev = -1;
+    bool cached = false;
     ~Owned() {
+      if (cached) {
+        std::lock_guard<std::mutex> lock(g_spare_mutex);
+        g_spare[dev].in_use = false;
+        return;
+      }
       if (level) (void)hipFree(level);
       if (flag) (void)hipFree(flag);
     }
   } own;
-  FDTD_HIP_CHECK(hipMalloc((void **)&own.level, vol * sizeof(float)));
-  FDTD_HIP_CHECK(hipMalloc((void **)&own.flag, sizeof(int)));
+  FDTD_HIP_CHECK(hipGetDevice(&own.dev));
+  if (own.dev >= 0 && own.dev < kMaxSpareDevices) {
+    std::lock_guard<std::mutex> lock(g_spare_mutex);
+    SpareLevel &sp = g_spare[own.dev];
+    if (!sp.in_use) {
+      if (sp.floats < vol + 1) {
+        if (sp.level) (void)hipFree(sp.level);
+        sp.level = nullptr;
+        sp.floats = 0;
+        if (hipMalloc((void **)&sp.level, (vol + 1) * sizeof(float)) == hipSuccess) sp.floats = vol + 1;
+        else (void)hipGetLastError();
+      }
+      if (sp.floats >= vol + 1) {
+        sp.in_use = true;
+        own.cached = true;
+        own.level = sp.level;
+        own.flag = (int *)(sp.level + vol);   // the word behind the level
+      }
+    }
+  }
+  if (!own.cached) {
+    FDTD_HIP_CHECK(hipMalloc((void **)&own.level, vol * sizeof(float)));
+    FDTD_HIP_CHECK(hipMalloc((void **)&own.flag, sizeof(int)));
+  }
   float *P[4] = {u, u + vol, u + 2 * vol, own.level};
   auto mod3 = [](int t) { return ((t % 3) + 3) % 3; };
   int cur = mod3(time_m), prev = mod3(time_m + 2), third = mod3(time_m + 1), spare = 3;
@@ -630,6 +673,16 @@ extern "C" void fdtd_hip_release_device_copies(void) {
     r.d.release();
   }
   g_resident.clear();
+  {
+    std::lock_guard<std::mutex> spare_lock(g_spare_mutex);
+    for (int dev = 0; dev < kMaxSpareDevices; ++dev) {
+      SpareLevel &sp = g_spare[dev];
+      if (!sp.level || sp.in_use) continue;
+      (void)hipSetDevice(dev);
+      (void)hipFree(sp.level);
+      sp = SpareLevel();
+    }
+  }
   (void)hipSetDevice(saved);
 }
 

@@ -357,8 +357,8 @@ int fdtd_hip_copy_shell(const struct fdtd_geom *g, float *dst_level, const float
  * which case nothing is timed).  This is the body of every Kernel_* operator between
  * its host-to-device and device-to-host copies (cuda.cu:232-314).  The call returns
  * after a final stream synchronise.  Beyond that: where it takes the two-step sweep
- * (boxes of 16 M cells and more) it allocates a fourth level buffer and a flag for the
- * duration of the call, reads the source positions back once (one small device-to-host
+ * (boxes of 16 M cells and more) it uses a fourth level buffer, allocated at the first such
+ * call on a device and kept until fdtd_hip_release_device_copies, reads the source positions back once (one small device-to-host
  * copy and a stream synchronise before the first step) and ends with up to four
  * level copies that put the three newest levels into their ring slots; where it takes
  * the one-launch-per-step loop (smaller boxes) it allocates a table of the sources and
