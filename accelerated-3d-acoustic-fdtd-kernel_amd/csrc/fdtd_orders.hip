@@ -1,27 +1,47 @@
-// fdtd_orders.hip — space orders 6 and 8 (and 4 through the same generic code).
+// fdtd_orders.hip — space orders 6, 8, 10 and 12 (and 4 through the same generic code).
 //
-// The reference driver is parameterised on STENCIL_ORDER, with HALO = STENCIL_ORDER cells of
-// padding per side (main.cpp:27-32,129-136), but every reference kernel hard-codes order 4
-// (openacc.cpp:102-107, cuda.cu:55, cuda_optimized.cu:34): there is no reference arithmetic for
-// the other orders, so their parity is unpinned.  What this file evaluates is the order-4
-// expression of openacc.cpp:159-164 with its pattern continued: the central second-difference
-// weights of the order as 9-digit float literals (the way the order-4 ones are printed), each axis
-// summed from the farthest pair of neighbours to the nearest, interior cell i at padded index
-// i + order.  With order 4 it returns the bits of the order-4 kernels (tested on every fixture).
+// The reference driver is parameterised on STENCIL_ORDER ("Can be 4, 6, 8, 10, 12"), with
+// HALO = STENCIL_ORDER cells of padding per side (main.cpp:27-32,129-136), but every reference
+// kernel hard-codes order 4 (openacc.cpp:102-107, cuda.cu:55, cuda_optimized.cu:34): there is no
+// reference arithmetic for the other orders, so their parity is unpinned.  What this file evaluates
+// is the order-4 expression of openacc.cpp:159-164 with its pattern continued: the central
+// second-difference weights of the order as 9-digit float literals (the way the order-4 ones are
+// printed), each axis summed from the farthest pair of neighbours to the nearest, interior cell i
+// at padded index i + order.  With order 4 it returns the bits of the order-4 kernels (tested on
+// every fixture).
 //
-// One thread per cell, z on the lanes, every operand from global memory (the shape of cuda.cu:61-108):
-// the register- and LDS-staged sweeps of the other files are written for radius 2.
+// Two kernels, same bits.  stencil_order_kernel: one thread per cell, z on the lanes, every operand
+// from global memory (the shape of cuda.cu:61-108), for small boxes and boxes that reach into the
+// padding.  stencil_order_march_kernel: a workgroup marches along x over a tile of rows; the 2R+1
+// planes of the x-direction live in registers, the current plane goes through LDS for the y- and
+// z-neighbours, so every value of u(t) is fetched from memory once per tile (plus the R rows on
+// either side of it), whatever the radius.
 #include "fdtd_device.h"
 
 #pragma clang fp contract(off)
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MAX_R = 6;
 template <int R> struct Weights;
-template <> struct Weights<2> { static constexpr float w[5] = {-2.50F, 1.333333330F, -8.33333333e-2F, 0.0F, 0.0F}; };
-template <> struct Weights<3> { static constexpr float w[5] = {-2.72222222F, 1.5F, -1.5e-1F, 1.11111111e-2F, 0.0F}; };
+template <> struct Weights<2> {
+  static constexpr float w[MAX_R + 1] = {-2.50F, 1.333333330F, -8.33333333e-2F, 0.0F, 0.0F, 0.0F, 0.0F};
+};
+template <> struct Weights<3> {
+  static constexpr float w[MAX_R + 1] = {-2.72222222F, 1.5F, -1.5e-1F, 1.11111111e-2F, 0.0F, 0.0F, 0.0F};
+};
 template <> struct Weights<4> {
-  static constexpr float w[5] = {-2.84722222F, 1.6F, -2.0e-1F, 2.53968254e-2F, -1.78571429e-3F};
+  static constexpr float w[MAX_R + 1] = {-2.84722222F, 1.6F, -2.0e-1F, 2.53968254e-2F, -1.78571429e-3F, 0.0F, 0.0F};
+};
+template <> struct Weights<5> {
+  static constexpr float w[MAX_R + 1] = {-2.92722222F, 1.66666667F,     -2.38095238e-1F, 3.96825397e-2F,
+                                         -4.96031746e-3F, 3.17460317e-4F, 0.0F};
+};
+template <> struct Weights<6> {
+  static constexpr float w[MAX_R + 1] = {-2.98277778F,    1.71428571F,    -2.67857143e-1F, 5.29100529e-2F,
+                                         -8.92857143e-3F, 1.03896104e-3F, -6.01250601e-5F};
 };
 
 template <int R>
@@ -48,12 +68,246 @@ __global__ __launch_bounds__(256) void stencil_order_kernel(StencilArgs a) {
   a.u2[c] = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * a.u1[c]) * mc) / mc;
 }
 
+// ---------------------------------------------------------------------------------
+// The marching sweep.  Workgroup = 8 waves; tile = TY = 8 RW rows of 256 cells (4 cells per lane, RW rows
+// per wave); x is cut into chunks, one workgroup per (tile, chunk).
+//
+// Registers of a lane, per row: ring[0..2R] = its 4 cells of the planes p-R .. p+R.  LDS: the plane p on
+// the TY + 2R rows around the tile, 256 + 2 ZC cells each (ZC = 4 or 8 >= R cells beyond the tile on either
+// side), double-buffered, one barrier per plane.  Per plane a lane issues the loads of the next iteration
+// first (its cells of plane p+R+1, of u(t-1) and m of plane p+1, and its share of the rows and cells around
+// the tile of plane p+1), then evaluates plane p, then hands plane p+1 to LDS.
+//
+// Cells beyond z_M or y_M: lanes and rows there work on clamped addresses and store nothing; the lanes
+// within R cells behind z_M hold the padding the last cells need.  16-byte accesses are issued at 4-byte
+// alignment (z_m is arbitrary), which global memory takes.
+// ---------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) Quad { float v[4]; };
+__device__ __forceinline__ f32x4 ldq(const float *p) {
+  const Quad q = *(const Quad *)p;
+  return f32x4{q.v[0], q.v[1], q.v[2], q.v[3]};
+}
+__device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {   // workgroups b, b+8, .. share an XCD
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = b & 7, j = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <int R, int RW>
+__global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a, int xchunk, int nyt, int nzt) {
+  constexpr int H = 2 * R, TY = 8 * RW, NROWS = TY + 2 * R;
+  constexpr int ZF = R > 4 ? 2 : 1;           // float4s beyond the tile per side
+  constexpr int ROWF4 = 64 + 2 * ZF;
+  constexpr int NPIECE = 2 * R * 64 + TY * 2 * ZF;   // float4s around the tile, per plane
+  constexpr int NPT = (NPIECE + 511) / 512;            // ... per thread
+  __shared__ f32x4 plane[2][NROWS * ROWF4];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nzt * nyt);
+  const int zb = a.z_m + zt * 256, yb = a.y_m + yt * TY;
+  const int x_begin = a.x_m + xc * xchunk, x_end = min(x_begin + xchunk - 1, a.x_M);
+  if (x_begin > x_end) return;
+  const int sy = (int)a.sy;
+  const long sx = a.sx;
+  // a column of 4 cells starting at z: its address is used as it is while z <= z_M + R (padding included)
+  auto zaddr = [&](int z) { return (z <= a.z_M + R ? z : zb) + H; };
+  auto yaddr = [&](int y) { return min(y, a.y_M + R) + H; };
+
+  // own cells
+  const int z0 = zb + 4 * lane;
+  const int nvalid = min(max(a.z_M + 1 - z0, 0), 4);
+  int own[RW];          // offset inside a plane
+  bool row_valid[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int y = yb + wave * RW + r;
+    row_valid[r] = y <= a.y_M;
+    own[r] = yaddr(y) * sy + zaddr(z0);
+  }
+  // share of the cells around the tile
+  int poff[NPT], pslot[NPT];
+  bool pvalid[NPT];
+#pragma unroll
+  for (int q = 0; q < NPT; ++q) {
+    const int i = (int)threadIdx.x + 512 * q;
+    pvalid[q] = i < NPIECE;
+    int y, z, slot;
+    if (i < 2 * R * 64) {            // rows below and above the tile
+      const int hr = i >> 6, col = i & 63;
+      y = hr < R ? yb - R + hr : yb + TY + (hr - R);
+      z = zb + 4 * col;
+      slot = (hr < R ? hr : TY + hr) * ROWF4 + ZF + col;
+    } else {                         // cells before and behind the tile, own rows
+      const int j = i - 2 * R * 64, row = (j / (2 * ZF)) % TY, k = j % (2 * ZF);
+      y = yb + row;
+      z = k < ZF ? zb - 4 * ZF + 4 * k : zb + 256 + 4 * (k - ZF);
+      slot = (R + row) * ROWF4 + (k < ZF ? k : 64 + k);
+    }
+    poff[q] = yaddr(y) * sy + zaddr(z);
+    pslot[q] = slot;
+  }
+
+  const float *u0p = a.u0 + (long)(x_begin + H) * sx;    // plane p of u(t)
+  const float *u1p = a.u1 + (long)(x_begin + H) * sx;
+  const float *mp = a.m + (long)(x_begin + H) * sx;
+  float *u2p = a.u2 + (long)(x_begin + H) * sx;
+
+  f32x4 ring[RW][2 * R + 1], u1c[RW], mc[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) ring[r][k] = ldq(u0p + (long)(k - R) * sx + own[r]);
+    u1c[r] = ldq(u1p + own[r]);
+    mc[r] = ldq(mp + own[r]);
+  }
+  {
+    f32x4 *buf = plane[x_begin & 1];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) buf[(R + wave * RW + r) * ROWF4 + ZF + lane] = ring[r][R];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q)
+      if (pvalid[q]) buf[pslot[q]] = ldq(u0p + poff[q]);
+  }
+  __syncthreads();
+
+  const float neg2r1 = -2.0F * a.r1;
+  for (int p = x_begin; p <= x_end; ++p) {
+    const f32x4 *cur = plane[p & 1];
+    f32x4 *nxt = plane[(p & 1) ^ 1];
+    // loads of the next iteration (planes p+1 and p+R+1 exist in the arrays even when p = x_end)
+    f32x4 around[NPT], rn[RW], u1n[RW], mn[RW];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) around[q] = ldq(u0p + sx + poff[q]);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      rn[r] = ldq(u0p + (long)(R + 1) * sx + own[r]);
+      u1n[r] = ldq(u1p + sx + own[r]);
+      mn[r] = ldq(mp + sx + own[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int row = R + wave * RW + r;
+      const f32x4 uc = ring[r][R];
+      const f32x4 r5 = Weights<R>::w[0] * uc;
+      f32x4 dxx = r5, dyy = r5, dzz = r5;
+      // the row of plane p: ZF float4s before the lane's cells, the cells, ZF float4s behind
+      float win[4 + 8 * ZF];
+#pragma unroll
+      for (int j = 0; j < ZF; ++j) {
+        const f32x4 l = cur[row * ROWF4 + lane + j], h = cur[row * ROWF4 + ZF + lane + 1 + j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          win[4 * j + c] = l[c];
+          win[4 * ZF + 4 + 4 * j + c] = h[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) win[4 * ZF + c] = uc[c];
+#pragma unroll
+      for (int k = R; k >= 1; --k) {
+        const float w = Weights<R>::w[k];
+        dxx = dxx + w * (ring[r][R - k] + ring[r][R + k]);
+        dyy = dyy + w * (cur[(row - k) * ROWF4 + ZF + lane] + cur[(row + k) * ROWF4 + ZF + lane]);
+        const f32x4 zm = f32x4{win[4 * ZF - k], win[4 * ZF + 1 - k], win[4 * ZF + 2 - k], win[4 * ZF + 3 - k]};
+        const f32x4 zp = f32x4{win[4 * ZF + k], win[4 * ZF + 1 + k], win[4 * ZF + 2 + k], win[4 * ZF + 3 + k]};
+        dzz = dzz + w * (zm + zp);
+      }
+      const f32x4 num = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * u1c[r]) * mc[r]);
+      const f32x4 o = f32x4{num.x / mc[r].x, num.y / mc[r].y, num.z / mc[r].z, num.w / mc[r].w};
+      if (row_valid[r]) {
+        float *dst = u2p + own[r];
+        if (nvalid == 4) {
+          Quad q4;
+          q4.v[0] = o.x; q4.v[1] = o.y; q4.v[2] = o.z; q4.v[3] = o.w;
+          *(Quad *)dst = q4;
+        } else {
+          if (nvalid > 0) dst[0] = o.x;
+          if (nvalid > 1) dst[1] = o.y;
+          if (nvalid > 2) dst[2] = o.z;
+        }
+      }
+    }
+    // plane p+1 into the other buffer, rings forward
+#pragma unroll
+    for (int r = 0; r < RW; ++r) nxt[(R + wave * RW + r) * ROWF4 + ZF + lane] = ring[r][R + 1];
+#pragma unroll
+    for (int q = 0; q < NPT; ++q)
+      if (pvalid[q]) nxt[pslot[q]] = around[q];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+#pragma unroll
+      for (int k = 0; k < 2 * R; ++k) ring[r][k] = ring[r][k + 1];
+      ring[r][2 * R] = rn[r];
+      u1c[r] = u1n[r];
+      mc[r] = mn[r];
+    }
+    u0p += sx; u1p += sx; mp += sx; u2p += sx;
+    __syncthreads();
+  }
+}
+
 int g_space_order = 0;   // 0: not set yet (FDTD_STENCIL_ORDER, else 4)
+
+bool order_supported(int order) { return order >= 4 && order <= 2 * MAX_R && order % 2 == 0; }
+
+int env_int_orders(const char *name, int fallback) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : fallback;
+}
+
+// Workgroups of the marching sweep that one compute unit holds at a time (registers and LDS decide).
+template <int R, int RW>
+int march_workgroups_per_cu() {
+  static int n = 0;
+  if (n == 0) {
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW>, 512, 0) != hipSuccess || v < 1) v = 1;
+    n = v;
+  }
+  return n;
+}
+
+template <int R, int RW>
+void launch_order_march(const StencilArgs &a, hipStream_t s) {
+  constexpr int TY = 8 * RW;
+  const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
+  const int nyt = (ey + TY - 1) / TY, nzt = (ez + 255) / 256;
+  const long tiles = (long)nyt * nzt;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long slots = (long)cus * march_workgroups_per_cu<R, RW>();
+  // x-chunks: enough workgroups to fill the device once, each chunk long enough that the 2R planes it
+  // loads before its first result stay a small part of its work
+  const int min_chunk = 8 * R;
+  long nchunks = (slots + tiles - 1) / tiles;
+  if (nchunks > ex / min_chunk) nchunks = ex / min_chunk;
+  if (nchunks < 1) nchunks = 1;
+  const int forced = env_int_orders("FDTD_ORDER_XCHUNK", 0);
+  const int xchunk = forced > 0 ? forced : (int)((ex + nchunks - 1) / nchunks);
+  nchunks = (ex + xchunk - 1) / xchunk;
+  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s, a, xchunk,
+                     nyt, nzt);
+}
+
+// The marching sweep takes boxes that stay inside the interior of the arrays (its 16-byte accesses reach up
+// to 8 cells beyond the box in z) and are large enough to fill the device; FDTD_ORDER_MARCH = 0 keeps
+// every box on the one-cell-per-thread kernel, 2 sends every box that fits.
+bool order_march_takes(const StencilArgs &a, int H) {
+  const int mode = env_int_orders("FDTD_ORDER_MARCH", 1);
+  if (mode == 0) return false;
+  if (a.x_m < 0 || a.y_m < 0 || a.z_m < 0 || a.x_M > a.nxp - 2 * H - 1 || a.y_M > a.nyp - 2 * H - 1 ||
+      a.z_M > a.nzp - 2 * H - 1)
+    return false;
+  if ((long)a.nyp * a.nzp >= (1L << 30)) return false;   // offsets inside a plane are ints
+  if (mode == 2) return true;
+  const long ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
+  return ez >= 96 && ex * ey * ez >= (1L << 20);
+}
 
 }  // namespace
 
 extern "C" int fdtd_hip_set_space_order(int order) {
-  if (order != 4 && order != 6 && order != 8) return (int)hipErrorInvalidValue;
+  if (!order_supported(order)) return (int)hipErrorInvalidValue;
   g_space_order = order;
   return 0;
 }
@@ -62,14 +316,14 @@ extern "C" int fdtd_hip_get_space_order(void) {
   if (g_space_order == 0) {
     const char *e = getenv("FDTD_STENCIL_ORDER");
     const int v = e ? atoi(e) : 4;
-    g_space_order = (v == 6 || v == 8) ? v : 4;
+    g_space_order = order_supported(v) ? v : 4;
   }
   return g_space_order;
 }
 
 int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
                               float *u2, int order, void *stream) {
-  if (!g || !m || !u0 || !u1 || !u2 || (order != 4 && order != 6 && order != 8)) return (int)hipErrorInvalidValue;
+  if (!g || !m || !u0 || !u1 || !u2 || !order_supported(order)) return (int)hipErrorInvalidValue;
   const int R = order / 2, H = order;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
   if (ex <= 0 || ey <= 0 || ez <= 0) return 0;
@@ -77,7 +331,6 @@ int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const f
   if (g->x_m + H - R < 0 || g->x_M + H + R > g->nxp - 1 || g->y_m + H - R < 0 || g->y_M + H + R > g->nyp - 1 ||
       g->z_m + H - R < 0 || g->z_M + H + R > g->nzp - 1)
     return (int)hipErrorInvalidValue;
-  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
   StencilArgs a;
   a.m = m; a.u0 = u0; a.u1 = u1; a.u2 = u2;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
@@ -88,11 +341,26 @@ int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const f
   a.r2 = 1.0F / (g->h_x * g->h_x);
   a.r3 = 1.0F / (g->h_y * g->h_y);
   a.r4 = 1.0F / (g->h_z * g->h_z);
-  const dim3 grid((ez + 63) / 64, (ey + 3) / 4, ex), block(64, 4, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (R == 2) hipLaunchKernelGGL(stencil_order_kernel<2>, grid, block, 0, s, a);
-  else if (R == 3) hipLaunchKernelGGL(stencil_order_kernel<3>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(stencil_order_kernel<4>, grid, block, 0, s, a);
+  if (order_march_takes(a, H)) {
+    switch (R) {
+      case 2: launch_order_march<2, 2>(a, s); break;
+      case 3: launch_order_march<3, 2>(a, s); break;
+      case 4: launch_order_march<4, 2>(a, s); break;
+      case 5: launch_order_march<5, 2>(a, s); break;
+      default: launch_order_march<6, 2>(a, s); break;
+    }
+    return (int)hipGetLastError();
+  }
+  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
+  const dim3 grid((ez + 63) / 64, (ey + 3) / 4, ex), block(64, 4, 1);
+  switch (R) {
+    case 2: hipLaunchKernelGGL(stencil_order_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(stencil_order_kernel<3>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(stencil_order_kernel<4>, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(stencil_order_kernel<5>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(stencil_order_kernel<6>, grid, block, 0, s, a); break;
+  }
   return (int)hipGetLastError();
 }
 
@@ -108,7 +376,7 @@ extern "C" int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const flo
                                             const float *src_coords, float *u, int t2, int time, int p_src_m,
                                             int p_src_M, int src_stride, int coord_stride, int order, void *stream) {
   if (p_src_M < p_src_m) return 0;
-  if (!g || !u || t2 < 0 || t2 > 2 || (order != 4 && order != 6 && order != 8)) return (int)hipErrorInvalidValue;
+  if (!g || !u || t2 < 0 || t2 > 2 || !order_supported(order)) return (int)hipErrorInvalidValue;
   const long vol = (long)g->nxp * g->nyp * g->nzp;
   return fdtd_inject_level_halo(g, m, src, src_coords, u + (long)t2 * vol, time, p_src_m, p_src_M, src_stride,
                                 coord_stride, 0, g->x_m - 1, g->x_M + 1, 0, 0, 0, order, stream);

@@ -255,20 +255,25 @@ void oracle_compare_fields(const float *test, const float *ref, size_t n,
 }
 
 /* ---------------------------------------------------------------------------------------------
- * Other space orders (6, 8).  The reference driver is parameterised on STENCIL_ORDER with
- * HALO = STENCIL_ORDER cells of padding per side (main.cpp:27-32,129-136), but every reference
- * kernel hard-codes order 4 (openacc.cpp:102-107, cuda.cu:55), so there is NO reference arithmetic
- * for orders 6 and 8: PARITY UNPINNED for them.  What is restated here is the order-4 expression
+ * Other space orders (6, 8, 10, 12).  The reference driver is parameterised on STENCIL_ORDER
+ * ("Can be 4, 6, 8, 10, 12") with HALO = STENCIL_ORDER cells of padding per side
+ * (main.cpp:27-32,129-136), but every reference kernel hard-codes order 4 (openacc.cpp:102-107,
+ * cuda.cu:55), so there is NO reference arithmetic for the other orders: PARITY UNPINNED for them.  What is restated here is the order-4 expression
  * (openacc.cpp:159-164) with its pattern continued: the central second-difference weights of the
  * order as 9-digit float literals, the way the order-4 ones are printed (-2.5, 1.33333333,
  * -8.33333333e-2), each axis summed from the farthest pair of neighbours to the nearest, padding
  * offset = order.  With order 4 this function produces the bits of oracle_section0 (checked by the
  * tests on every fixture), which pins the generic form itself.
  * ------------------------------------------------------------------------------------------- */
-static const float k_order_weights[3][5] = {
-    /* order 4 */ {-2.50F, 1.333333330F, -8.33333333e-2F, 0.0F, 0.0F},
-    /* order 6 */ {-2.72222222F, 1.5F, -1.5e-1F, 1.11111111e-2F, 0.0F},
-    /* order 8 */ {-2.84722222F, 1.6F, -2.0e-1F, 2.53968254e-2F, -1.78571429e-3F},
+static const float k_order_weights[5][7] = {
+    /* order 4 */ {-2.50F, 1.333333330F, -8.33333333e-2F, 0.0F, 0.0F, 0.0F, 0.0F},
+    /* order 6 */ {-2.72222222F, 1.5F, -1.5e-1F, 1.11111111e-2F, 0.0F, 0.0F, 0.0F},
+    /* order 8 */ {-2.84722222F, 1.6F, -2.0e-1F, 2.53968254e-2F, -1.78571429e-3F, 0.0F, 0.0F},
+    /* order 10: -5269/1800, 5/3, -5/21, 5/126, -5/1008, 1/3150 */
+    {-2.92722222F, 1.66666667F, -2.38095238e-1F, 3.96825397e-2F, -4.96031746e-3F, 3.17460317e-4F, 0.0F},
+    /* order 12: -5369/1800, 12/7, -15/56, 10/189, -1/112, 2/1925, -1/16632 */
+    {-2.98277778F, 1.71428571F, -2.67857143e-1F, 5.29100529e-2F, -8.92857143e-3F, 1.03896104e-3F,
+     -6.01250601e-5F},
 };
 
 static void oracle_section0_order(int order, const float *restrict m, const float *restrict u0,
@@ -329,11 +334,11 @@ static void oracle_section1_order(int H, const float *restrict m, const float *r
         }
 }
 
-/* The operator for space order 4, 6 or 8 on arrays padded by `order` cells per side. */
+/* The operator for space order 4, 6, 8, 10 or 12 on arrays padded by `order` cells per side. */
 int Oracle_Kernel_SpaceOrder(FDTD_OPERATOR_ARGS, int order) {
   (void)deviceid;
   (void)devicerm;
-  if (order != 4 && order != 6 && order != 8) return 1;
+  if (order < 4 || order > 12 || order % 2) return 1;
   const long nxp = u_vec->size[1], nyp = u_vec->size[2], nzp = u_vec->size[3];
   const long vol = nxp * nyp * nzp;
   float *u = (float *)u_vec->data;

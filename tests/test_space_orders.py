@@ -1,11 +1,12 @@
-"""Space orders 6 and 8 (the reference driver's STENCIL_ORDER, main.cpp:27-32).
+"""Space orders 6, 8, 10 and 12 (the reference driver's STENCIL_ORDER, main.cpp:27-32).
 
-PARITY UNPINNED for orders 6 and 8: no reference kernel implements them (openacc.cpp:102-107 hard-codes
+PARITY UNPINNED for orders above 4: no reference kernel implements them (openacc.cpp:102-107 hard-codes
 order 4), so there is nothing of the reference's to compare with.  What is pinned: the generic
 restatement run at order 4 gives the fixtures' bits (so the form — loop order, padding arithmetic,
-scatter on a wider padding — is the reference's), the weights of orders 6 and 8 are the standard central
-second-difference weights (checked through the truncation error on a smooth field), and the HIP kernels
-give the generic oracle's bits for every order."""
+scatter on a wider padding — is the reference's), the weights of the higher orders are the standard central
+second-difference weights (exact on polynomials up to their degree; the truncation error on a sine shrinks
+with the order), and the HIP kernels — the one-cell-per-thread sweep and the marching sweep — give the
+generic oracle's bits for every order."""
 import ctypes as C
 
 import numpy as np
@@ -56,7 +57,7 @@ def test_weights_are_the_central_second_difference_weights(pkg):
     -k^2 sin(k z) up to truncation error, which shrinks with the order (h^4, h^6, h^8)."""
     n, hz, k = (4, 4, 96), 0.5, 1.3
     errs = {}
-    for order in (4, 6, 8):
+    for order in (4, 6, 8, 10, 12):
         H = order
         shape = tuple(v + 2 * H for v in n)
         z = (np.arange(shape[2]) - H) * hz
@@ -74,11 +75,33 @@ def test_weights_are_the_central_second_difference_weights(pkg):
     # leading truncation terms k^2 (kh)^4 / 90, k^2 (kh)^6 / 560, k^2 (kh)^8 / 3150 = 3.4e-3, 2.3e-4, 1.7e-5;
     # fp32 round-off contributes about 1.5e-4
     assert 2e-3 < errs[4] < 5e-3, errs
-    assert errs[6] < 6e-4 and errs[8] < 3e-4, errs
+    assert errs[6] < 6e-4 and errs[8] < 3e-4 and errs[10] < 3e-4 and errs[12] < 3e-4, errs
+
+
+def test_weight_tables_sum_to_zero_and_reproduce_the_second_moment():
+    """The printed weights of every order, as the float literals of the sources: sum w = 0 (constants have no
+    Laplacian), sum w k^2 = 2 (z^2 has Laplacian 2), sum w k^(2j) = 0 for 2 <= j <= order/2 (the order of the
+    scheme), each to the rounding of nine printed digits."""
+    import re
+    src = open(ob.ORACLE_DIR + "/fdtd_oracle.c").read()
+    rows = re.search(r"k_order_weights\[5\]\[7\] = \{(.*?)\};", src, re.S).group(1)
+    rows = re.sub(r"/\*.*?\*/", "", rows, flags=re.S)
+    tables = [[float(v.rstrip("F")) for v in re.findall(r"-?\d[\d.e-]*F", row)] for row in re.findall(r"\{(.*?)\}", rows, re.S)]
+    assert len(tables) == 5 and all(len(t) == 7 for t in tables)
+    hip = open(ob.ROOT + "/accelerated-3d-acoustic-fdtd-kernel_amd/csrc/fdtd_orders.hip").read()
+    for R, w in zip(range(2, 7), tables):
+        assert all(v == 0.0 for v in w[R + 1:]) and w[R] != 0.0
+        assert abs(w[0] + 2 * sum(w[1:])) < 2e-8, (R, w)
+        assert abs(sum(2 * w[k] * k * k for k in range(1, R + 1)) - 2.0) < 5e-8, (R, w)
+        for j in range(2, R + 1):
+            assert abs(sum(2 * w[k] * float(k) ** (2 * j) for k in range(1, R + 1))) < 3e-6 * 6.0 ** (2 * j - 4), (R, j)
+        # the HIP source holds the same literals
+        body = re.search(r"struct Weights<%d> \{(.*?)\};\n\};" % R, hip, re.S).group(1)
+        assert [float(v.rstrip("F")) for v in re.findall(r"-?\d[\d.e-]*F", body)] == w, R
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("order", [4, 6, 8])
+@pytest.mark.parametrize("order", [4, 6, 8, 10, 12])
 def test_operators_at_space_order(pkg, hiplib, order):
     """All three operators with the process-wide space order set: the generic oracle's bits on a non-cubic box
     with an edge source, on a sub-range, and on a run long enough for the timers."""
@@ -101,7 +124,61 @@ def test_operators_at_space_order(pkg, hiplib, order):
             assert rc == 1
     finally:
         assert hiplib.fdtd_hip_set_space_order(4) == 0
-    assert hiplib.fdtd_hip_set_space_order(5) == 1 and hiplib.fdtd_hip_get_space_order() == 4
+    assert hiplib.fdtd_hip_set_space_order(5) == 1 and hiplib.fdtd_hip_set_space_order(14) == 1
+    assert hiplib.fdtd_hip_get_space_order() == 4
+
+
+def _one_sweep(pkg, hiplib, order, n, bounds, seed, monkeypatch=None):
+    """One sweep of fdtd_hip_stencil_step_order against the oracle's on a random field; returns the two fields."""
+    import torch
+    u0, m, _, _, kw = padded_case(order, n, 1, 0, seed, bounds)
+    u_ref = u0.copy()
+    ob.run_oracle_order(order, m, None, None, u_ref, **kw)
+    b = kw["bounds"]
+    shape = u0.shape[1:]
+    g = pkg.Geom(*shape, *b, kw["dt"], *kw["h"], 0.0, 0.0, 0.0)
+    u_d, m_d = torch.from_numpy(u0).cuda(), torch.from_numpy(m).cuda()
+    assert hiplib.fdtd_hip_stencil_step_order(C.byref(g), m_d.data_ptr(), u_d.data_ptr(), 0, 2, 1, order, None) == 0
+    torch.cuda.synchronize()
+    return u_d.cpu().numpy(), u_ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [4, 6, 8, 10, 12])
+@pytest.mark.parametrize("n,bounds", [
+    ((40, 64, 256), None),                           # full tiles
+    ((33, 50, 300), None),                           # rows end inside the second z-tile, rows beyond the last y-tile
+    ((36, 37, 131), (2, 33, 3, 30, 5, 127)),         # sub-range, z_m not a multiple of 4
+    ((70, 16, 515), (0, 69, 0, 15, 1, 513)),         # three z-tiles, the last one a single cell wide; several x-chunks
+])
+def test_marching_sweep_gives_the_oracle_bits(pkg, hiplib, monkeypatch, order, n, bounds):
+    """The marching sweep (x-ring in registers, current plane in LDS) on boxes that exercise its masks, forced on
+    whatever the size of the box, with short x-chunks so that several chunks meet."""
+    monkeypatch.setenv("FDTD_ORDER_MARCH", "2")
+    monkeypatch.setenv("FDTD_ORDER_XCHUNK", "16")
+    u, u_ref = _one_sweep(pkg, hiplib, order, n, bounds, 900 + order)
+    assert ob.bits_equal(u, u_ref), (order, n)
+    # the cells outside the box are untouched
+    monkeypatch.setenv("FDTD_ORDER_MARCH", "0")
+    u_naive, _ = _one_sweep(pkg, hiplib, order, n, bounds, 900 + order)
+    assert ob.bits_equal(u_naive, u_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [6, 12])
+def test_operator_at_space_order_on_a_box_the_marching_sweep_takes(pkg, hiplib, order):
+    """The whole operator (sweeps + scatters, timers) on a box large enough for the marching sweep by itself."""
+    assert hiplib.fdtd_hip_set_space_order(order) == 0
+    try:
+        u0, m, src, coords, kw = padded_case(order, (48, 160, 192), 8, 3, 70 + order, None, True)
+        u_ref = u0.copy()
+        ob.run_oracle_order(order, m, src, coords, u_ref, **kw)
+        u = u0.copy()
+        rc, prof = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, **kw)
+        assert rc == 0 and prof.section0 > 0
+        assert ob.bits_equal(u, u_ref)
+    finally:
+        assert hiplib.fdtd_hip_set_space_order(4) == 0
 
 
 @pytest.mark.gpu
