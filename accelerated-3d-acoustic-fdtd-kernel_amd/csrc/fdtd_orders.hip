@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void stencil_order_kernel(StencilArgs a) {
 // alignment (z_m is arbitrary), which global memory takes.
 // ---------------------------------------------------------------------------------
 struct __attribute__((packed, aligned(4))) Quad { float v[4]; };
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // a float4 at 4-byte alignment
 __device__ __forceinline__ f32x4 ldq(const float *p) {
   const Quad q = *(const Quad *)p;
   return f32x4{q.v[0], q.v[1], q.v[2], q.v[3]};
@@ -92,8 +93,9 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {   // workgro
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-template <int R, int RW>
+template <int R, int RW, int D, bool NT>
 __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a, int xchunk, int nyt, int nzt) {
+  static_assert(D >= 1 && D <= R, "planes up to x_M + R + D must exist");
   constexpr int H = 2 * R, TY = 8 * RW, NROWS = TY + 2 * R;
   constexpr int ZF = R > 4 ? 2 : 1;           // float4s beyond the tile per side
   constexpr int ROWF4 = 64 + 2 * ZF;
@@ -152,14 +154,24 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   const float *mp = a.m + (long)(x_begin + H) * sx;
   float *u2p = a.u2 + (long)(x_begin + H) * sx;
 
-  f32x4 ring[RW][2 * R + 1], u1c[RW], mc[RW];
+  // ring[k]: the lane's cells of plane p - R + k; uq[j], mq[j]: u(t-1) and m of plane p + j; aq[j]: the
+  // thread's share of the cells around the tile, plane p + 1 + j.  Everything up to D planes ahead of what
+  // the current plane needs is in registers or in flight.
+  f32x4 ring[RW][2 * R + D], uq[RW][D], mq[RW][D], aq[NPT][D];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
 #pragma unroll
-    for (int k = 0; k <= 2 * R; ++k) ring[r][k] = ldq(u0p + (long)(k - R) * sx + own[r]);
-    u1c[r] = ldq(u1p + own[r]);
-    mc[r] = ldq(mp + own[r]);
+    for (int k = 0; k < 2 * R + D; ++k) ring[r][k] = ldq(u0p + (long)(k - R) * sx + own[r]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      uq[r][j] = ldq(u1p + (long)j * sx + own[r]);
+      mq[r][j] = ldq(mp + (long)j * sx + own[r]);
+    }
   }
+#pragma unroll
+  for (int q = 0; q < NPT; ++q)
+#pragma unroll
+    for (int j = 0; j + 1 < D; ++j) aq[q][j] = ldq(u0p + (long)(j + 1) * sx + poff[q]);
   {
     f32x4 *buf = plane[x_begin & 1];
 #pragma unroll
@@ -174,15 +186,15 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   for (int p = x_begin; p <= x_end; ++p) {
     const f32x4 *cur = plane[p & 1];
     f32x4 *nxt = plane[(p & 1) ^ 1];
-    // loads of the next iteration (planes p+1 and p+R+1 exist in the arrays even when p = x_end)
-    f32x4 around[NPT], rn[RW], u1n[RW], mn[RW];
+    // loads for D planes ahead (the planes up to x_M + R + D exist in the arrays: D <= R)
+    f32x4 rn[RW], un[RW], mn[RW];
 #pragma unroll
-    for (int q = 0; q < NPT; ++q) around[q] = ldq(u0p + sx + poff[q]);
+    for (int q = 0; q < NPT; ++q) aq[q][D - 1] = ldq(u0p + (long)D * sx + poff[q]);
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      rn[r] = ldq(u0p + (long)(R + 1) * sx + own[r]);
-      u1n[r] = ldq(u1p + sx + own[r]);
-      mn[r] = ldq(mp + sx + own[r]);
+      rn[r] = ldq(u0p + (long)(R + D) * sx + own[r]);
+      un[r] = ldq(u1p + (long)D * sx + own[r]);
+      mn[r] = ldq(mp + (long)D * sx + own[r]);
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -212,14 +224,16 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
         const f32x4 zp = f32x4{win[4 * ZF + k], win[4 * ZF + 1 + k], win[4 * ZF + 2 + k], win[4 * ZF + 3 + k]};
         dzz = dzz + w * (zm + zp);
       }
-      const f32x4 num = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * u1c[r]) * mc[r]);
-      const f32x4 o = f32x4{num.x / mc[r].x, num.y / mc[r].y, num.z / mc[r].z, num.w / mc[r].w};
+      const f32x4 mc = mq[r][0];
+      const f32x4 num = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * uq[r][0]) * mc);
+      const f32x4 o = f32x4{num.x / mc.x, num.y / mc.y, num.z / mc.z, num.w / mc.w};
       if (row_valid[r]) {
         float *dst = u2p + own[r];
         if (nvalid == 4) {
           Quad q4;
           q4.v[0] = o.x; q4.v[1] = o.y; q4.v[2] = o.z; q4.v[3] = o.w;
-          *(Quad *)dst = q4;
+          if (NT) __builtin_nontemporal_store(o, (f32x4_a4 *)dst);
+          else *(Quad *)dst = q4;
         } else {
           if (nvalid > 0) dst[0] = o.x;
           if (nvalid > 1) dst[1] = o.y;
@@ -231,15 +245,23 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
 #pragma unroll
     for (int r = 0; r < RW; ++r) nxt[(R + wave * RW + r) * ROWF4 + ZF + lane] = ring[r][R + 1];
 #pragma unroll
-    for (int q = 0; q < NPT; ++q)
-      if (pvalid[q]) nxt[pslot[q]] = around[q];
+    for (int q = 0; q < NPT; ++q) {
+      if (pvalid[q]) nxt[pslot[q]] = aq[q][0];
+#pragma unroll
+      for (int j = 0; j + 1 < D; ++j) aq[q][j] = aq[q][j + 1];
+    }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
 #pragma unroll
-      for (int k = 0; k < 2 * R; ++k) ring[r][k] = ring[r][k + 1];
-      ring[r][2 * R] = rn[r];
-      u1c[r] = u1n[r];
-      mc[r] = mn[r];
+      for (int k = 0; k + 1 < 2 * R + D; ++k) ring[r][k] = ring[r][k + 1];
+      ring[r][2 * R + D - 1] = rn[r];
+#pragma unroll
+      for (int j = 0; j + 1 < D; ++j) {
+        uq[r][j] = uq[r][j + 1];
+        mq[r][j] = mq[r][j + 1];
+      }
+      uq[r][D - 1] = un[r];
+      mq[r][D - 1] = mn[r];
     }
     u0p += sx; u1p += sx; mp += sx; u2p += sx;
     __syncthreads();
@@ -256,18 +278,18 @@ int env_int_orders(const char *name, int fallback) {
 }
 
 // Workgroups of the marching sweep that one compute unit holds at a time (registers and LDS decide).
-template <int R, int RW>
+template <int R, int RW, int D, bool NT>
 int march_workgroups_per_cu() {
   static int n = 0;
   if (n == 0) {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW>, 512, 0) != hipSuccess || v < 1) v = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW, D, NT>, 512, 0) != hipSuccess || v < 1) v = 1;
     n = v;
   }
   return n;
 }
 
-template <int R, int RW>
+template <int R, int RW, int D, bool NT>
 void launch_order_march(const StencilArgs &a, hipStream_t s) {
   constexpr int TY = 8 * RW;
   const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
@@ -275,17 +297,26 @@ void launch_order_march(const StencilArgs &a, hipStream_t s) {
   const long tiles = (long)nyt * nzt;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long slots = (long)cus * march_workgroups_per_cu<R, RW>();
-  // x-chunks: enough workgroups to fill the device once, each chunk long enough that the 2R planes it
-  // loads before its first result stay a small part of its work
-  const int min_chunk = 8 * R;
-  long nchunks = (slots + tiles - 1) / tiles;
-  if (nchunks > ex / min_chunk) nchunks = ex / min_chunk;
-  if (nchunks < 1) nchunks = 1;
+  const long slots = (long)cus * march_workgroups_per_cu<R, RW, D, NT>();
+  // x-chunks: the device works through ceil(workgroups / slots) rounds of (chunk length + lead-in), where
+  // the lead-in — the 2R planes a chunk loads before its first result, without arithmetic — counts as R
+  // planes.  Take the number of chunks that minimises the product.
+  long nchunks = 1;
+  double best = 0.0;
+  for (long n = 1; n <= ex && n <= 4096; ++n) {
+    const long len = (ex + n - 1) / n;
+    if (n > 1 && len < 4) break;
+    const long rounds = (tiles * ((ex + len - 1) / len) + slots - 1) / slots;
+    const double cost = (double)rounds * (double)(len + R + 1);
+    if (n == 1 || cost < best) {
+      best = cost;
+      nchunks = n;
+    }
+  }
   const int forced = env_int_orders("FDTD_ORDER_XCHUNK", 0);
   const int xchunk = forced > 0 ? forced : (int)((ex + nchunks - 1) / nchunks);
   nchunks = (ex + xchunk - 1) / xchunk;
-  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s, a, xchunk,
+  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s, a, xchunk,
                      nyt, nzt);
 }
 
@@ -301,7 +332,9 @@ bool order_march_takes(const StencilArgs &a, int H) {
   if ((long)a.nyp * a.nzp >= (1L << 30)) return false;   // offsets inside a plane are ints
   if (mode == 2) return true;
   const long ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
-  return ez >= 96 && ex * ey * ez >= (1L << 20);
+  // measured on MI355X: from 256^3 cells on the marching sweep is the faster one at every order; below, the
+  // one-cell-per-thread sweep finds its operands in the caches
+  return ez >= 160 && ex * ey * ez >= (long)env_int_orders("FDTD_ORDER_MARCH_MIN_CELLS", 12000000);
 }
 
 }  // namespace
@@ -343,13 +376,23 @@ int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const f
   a.r4 = 1.0F / (g->h_z * g->h_z);
   hipStream_t s = (hipStream_t)stream;
   if (order_march_takes(a, H)) {
+    // non-temporal stores: the level written is not read again before the next sweep has streamed the
+    // whole field through the caches (FDTD_ORDER_NT = 0 keeps plain stores, for measurements)
+    const int nt = env_int_orders("FDTD_ORDER_NT", 1);
+#define ORDER_MARCH(R_)                                          \
+  case R_:                                                       \
+    if (nt) launch_order_march<R_, 2, 1, true>(a, s);            \
+    else launch_order_march<R_, 2, 1, false>(a, s);              \
+    break;
     switch (R) {
-      case 2: launch_order_march<2, 2>(a, s); break;
-      case 3: launch_order_march<3, 2>(a, s); break;
-      case 4: launch_order_march<4, 2>(a, s); break;
-      case 5: launch_order_march<5, 2>(a, s); break;
-      default: launch_order_march<6, 2>(a, s); break;
+      ORDER_MARCH(2)
+      ORDER_MARCH(3)
+      ORDER_MARCH(4)
+      ORDER_MARCH(5)
+      default:
+      ORDER_MARCH(6)
     }
+#undef ORDER_MARCH
     return (int)hipGetLastError();
   }
   if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;

@@ -166,8 +166,10 @@ def test_marching_sweep_gives_the_oracle_bits(pkg, hiplib, monkeypatch, order, n
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("order", [6, 12])
-def test_operator_at_space_order_on_a_box_the_marching_sweep_takes(pkg, hiplib, order):
-    """The whole operator (sweeps + scatters, timers) on a box large enough for the marching sweep by itself."""
+def test_operator_at_space_order_on_a_box_the_marching_sweep_takes(pkg, hiplib, monkeypatch, order):
+    """The whole operator (sweeps + scatters, timers) with the marching sweep chosen by the size rule (lowered to
+    the size of this box: by default it starts at 12 M cells)."""
+    monkeypatch.setenv("FDTD_ORDER_MARCH_MIN_CELLS", "1000000")
     assert hiplib.fdtd_hip_set_space_order(order) == 0
     try:
         u0, m, src, coords, kw = padded_case(order, (48, 160, 192), 8, 3, 70 + order, None, True)
