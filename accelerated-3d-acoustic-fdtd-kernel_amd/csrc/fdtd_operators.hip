@@ -353,8 +353,8 @@ static int time_loop_impl(bool h16, const struct fdtd_geom *g, const float *m, c
   hipStream_t s = (hipStream_t)stream;
   const bool has_src = (p_src_M >= p_src_m) && src && src_coords;
   if (p_src_M >= p_src_m && !has_src) return (int)hipErrorInvalidValue;
-  // Space orders 6 and 8 (fdtd_hip_set_space_order / FDTD_STENCIL_ORDER): arrays padded by `order` cells,
-  // one sweep and one scatter per step through the generic one-cell-per-thread kernel.
+  // Space orders above 4 (fdtd_hip_set_space_order / FDTD_STENCIL_ORDER): arrays padded by `order` cells,
+  // one sweep (fdtd_orders.hip: marching or one cell per thread, by size) and one scatter per step.
   const int order = fdtd_hip_get_space_order();
   if (order != FDTD_STENCIL_ORDER) {
     if (h16) return (int)hipErrorInvalidValue;

@@ -122,15 +122,18 @@ void fdtd_hip_release_device_copies(void);
  * device, time loop, copy to the host. */
 void fdtd_hip_last_call_phases(double out_ms[4]);
 
-/* Space order of the operators and of fdtd_hip_time_loop: 4 (default), 6 or 8.  The reference driver
- * is parameterised on STENCIL_ORDER with HALO = STENCIL_ORDER cells of padding per side
+/* Space order of the operators and of fdtd_hip_time_loop: 4 (default), 6, 8, 10 or 12, the values the
+ * reference driver's STENCIL_ORDER can take, with HALO = STENCIL_ORDER cells of padding per side
  * (main.cpp:27-32,129-136): a driver built with -DSTENCIL_ORDER=8 hands over arrays padded by 8 cells
  * and interior cell i lives at padded index i + 8.  No reference kernel implements any order but 4
- * (openacc.cpp:102-107), so orders 6 and 8 have no reference arithmetic (parity unpinned): they
+ * (openacc.cpp:102-107), so the higher orders have no reference arithmetic (parity unpinned): they
  * evaluate the order-4 expression of openacc.cpp:159-164 with the central second-difference weights
- * of their order (9-digit float literals, farthest neighbours first), through a one-cell-per-thread
- * kernel.  The order is process-wide: set it before the operators are called (or export
- * FDTD_STENCIL_ORDER); fp16 storage, the two-step sweep and the multi-GPU operator exist for order 4 only. */
+ * of their order (9-digit float literals, farthest neighbours first) — boxes of 12 M cells and more
+ * through a sweep that marches along x with the 2R+1 planes of the x direction in registers and the
+ * current plane in LDS, smaller ones through a one-cell-per-thread kernel; same bits.  The order is
+ * process-wide: set it before the operators are called (or export FDTD_STENCIL_ORDER); fp16 storage,
+ * the two-step sweep and the multi-GPU operator exist for order 4 only.  Any other value is refused
+ * (non-zero return) and leaves the order as it was. */
 int fdtd_hip_set_space_order(int order);
 int fdtd_hip_get_space_order(void);
 /* The forward operator of a Devito-style acoustic propagator around the same path: the update with an

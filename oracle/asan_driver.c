@@ -3,7 +3,7 @@
  *
  * Runs the CPU oracle (fdtd_oracle.c, built with -fsanitize=address) on small problems chosen for their
  * index arithmetic: sources in the outermost cell (scatter into the first halo layer, openacc.cpp:192),
- * sub-ranges, one-cell boxes, space orders 6 and 8; then, when built with FDTD_ASAN_WITH_ENGINE, the host
+ * sub-ranges, one-cell boxes, space orders 6 to 12; then, when built with FDTD_ASAN_WITH_ENGINE, the host
  * code of the engine library (libfdtd_hip.so built with -Xarch_host -fsanitize=address): input generators,
  * parity metrics, the shape logic of the two-step sweep and the operators' argument checks, which need no
  * GPU (an operator called without a device must return an error code, not crash).
@@ -56,7 +56,7 @@ int main(void) {
   int fails = 0;
   const int sub[6] = {1, 5, 2, 6, 0, 9};
   const int one[6] = {3, 3, 3, 3, 3, 3};
-  for (int order = 4; order <= 8; order += 2) {
+  for (int order = 4; order <= 12; order += 2) {
     fails += run_case(order, 9, 8, 11, 7, 3, NULL) != 0;
     fails += run_case(order, 9, 8, 11, 7, 2, sub) != 0;
     fails += run_case(order, 7, 7, 7, 3, 0, one) != 0;

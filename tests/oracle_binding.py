@@ -75,7 +75,7 @@ def run_oracle(m, src, coords, u, **kw):
 
 
 def run_oracle_order(order, m, src, coords, u, **kw):
-    """The oracle for space order 4, 6 or 8 (arrays padded by `order` cells per side); keyword interface of
+    """The oracle for space order 4, 6, 8, 10 or 12 (arrays padded by `order` cells per side); keyword interface of
     pkg.run_operator except that `bounds` is required when the padding is not 4."""
     pkg = load_package()
     fn = oracle().Oracle_Kernel_SpaceOrder
