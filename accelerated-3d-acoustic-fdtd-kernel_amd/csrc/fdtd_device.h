@@ -37,7 +37,7 @@ struct InjectArgs {
   int x_shift, x_lo, x_hi;
   int target_mode;  // 0: all admitted corners; 1: only those landing outside the domain's box; 2: only inside
   int gx_m, gx_M;   // planes of the domain's box in the coordinates of the source positions (target_mode != 0)
-  int halo;         // cells of padding per side of the arrays (FDTD_HALO; the space order for orders 6 and 8)
+  int halo;         // cells of padding per side of the arrays (FDTD_HALO; the space order for the higher orders)
 };
 
 #define FDTD_HIP_CHECK(expr)                  \
@@ -60,9 +60,13 @@ int fdtd_inject_level_halo(const struct fdtd_geom *g, const float *m, const floa
                            const float *src_coords, float *level, int time, int p_src_m, int p_src_M,
                            int src_stride, int coord_stride, int x_shift, int x_lo, int x_hi, int target_mode,
                            int gx_m, int gx_M, int halo, void *stream);
-// fdtd_orders.hip: one sweep of space order 4, 6 or 8 on arrays padded by `order` cells per side.
+// fdtd_orders.hip: one sweep of space order 4 .. 12 on arrays padded by `order` cells per side.
 int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
                               float *u2, int order, void *stream);
+
+// fdtd_orders.hip: the order-4 sweep with the damping term of fdtd_forward.hip through the marching kernel;
+// returns -1 without launching anything when the box is not one that kernel takes.
+int fdtd_damped_march(const StencilArgs &a, const float *damp, float dt, float r0, void *stream);
 
 extern "C" int fdtd_hip_get_space_order(void);
 

@@ -10,8 +10,8 @@
 // (damp = 0: the reference expression), and the receiver interpolation is the transpose of the scatter of
 // openacc.cpp:185-196 (same positions, weights, loop order and bounds test; a corner outside the bounds
 // contributes nothing).  Receivers sample the level the step started from, u(time), as a generated
-// Devito operator does.  One cell per thread / one receiver per thread; the register- and LDS-staged
-// sweeps serve the undamped update only.
+// Devito operator does.  The damped update of large boxes runs through the marching sweep of
+// fdtd_orders.hip (same expression, same bits), smaller ones one cell per thread; one receiver per thread.
 #include <math.h>
 
 #include <vector>
@@ -103,7 +103,6 @@ extern "C" int fdtd_hip_stencil_step_damped(const struct fdtd_geom *g, const flo
   if (g->x_m + FDTD_HALO - 2 < 0 || g->x_M + FDTD_HALO + 2 > g->nxp - 1 || g->y_m + FDTD_HALO - 2 < 0 ||
       g->y_M + FDTD_HALO + 2 > g->nyp - 1 || g->z_m + FDTD_HALO - 2 < 0 || g->z_M + FDTD_HALO + 2 > g->nzp - 1)
     return (int)hipErrorInvalidValue;
-  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
   const long vol = (long)g->nxp * g->nyp * g->nzp;
   DampedArgs a;
   a.s.m = m; a.s.u0 = u + t0 * vol; a.s.u1 = u + t1 * vol; a.s.u2 = u + t2 * vol;
@@ -116,6 +115,10 @@ extern "C" int fdtd_hip_stencil_step_damped(const struct fdtd_geom *g, const flo
   a.s.r3 = 1.0F / (g->h_y * g->h_y);
   a.s.r4 = 1.0F / (g->h_z * g->h_z);
   a.damp = damp; a.dt = g->dt; a.r0 = 1.0F / g->dt;
+  // large boxes: the marching sweep (x-ring in registers, plane in LDS), same expression, same bits
+  const int rc = fdtd_damped_march(a.s, damp, a.dt, a.r0, stream);
+  if (rc >= 0) return rc;
+  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(stencil_damped_kernel, dim3((ez + 63) / 64, (ey + 3) / 4, ex), dim3(64, 4, 1), 0,
                      (hipStream_t)stream, a);
   return (int)hipGetLastError();

@@ -93,8 +93,14 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {   // workgro
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-template <int R, int RW, int D, bool NT>
-__global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a, int xchunk, int nyt, int nzt) {
+// DAMPED: the update with an absorbing sponge of fdtd_forward.hip (damping field of the shape of m).
+struct DampTerm {
+  const float *damp;
+  float dt, r0;   // r0 = 1 / dt
+};
+template <int R, int RW, int D, bool NT, bool DAMPED = false>
+__global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a, int xchunk, int nyt, int nzt,
+                                                                  DampTerm dm) {
   static_assert(D >= 1 && D <= R, "planes up to x_M + R + D must exist");
   constexpr int H = 2 * R, TY = 8 * RW, NROWS = TY + 2 * R;
   constexpr int ZF = R > 4 ? 2 : 1;           // float4s beyond the tile per side
@@ -153,11 +159,12 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   const float *u1p = a.u1 + (long)(x_begin + H) * sx;
   const float *mp = a.m + (long)(x_begin + H) * sx;
   float *u2p = a.u2 + (long)(x_begin + H) * sx;
+  const float *dp = DAMPED ? dm.damp + (long)(x_begin + H) * sx : nullptr;
 
   // ring[k]: the lane's cells of plane p - R + k; uq[j], mq[j]: u(t-1) and m of plane p + j; aq[j]: the
   // thread's share of the cells around the tile, plane p + 1 + j.  Everything up to D planes ahead of what
   // the current plane needs is in registers or in flight.
-  f32x4 ring[RW][2 * R + D], uq[RW][D], mq[RW][D], aq[NPT][D];
+  f32x4 ring[RW][2 * R + D], uq[RW][D], mq[RW][D], aq[NPT][D], dq[RW][DAMPED ? D : 1];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
 #pragma unroll
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
     for (int j = 0; j < D; ++j) {
       uq[r][j] = ldq(u1p + (long)j * sx + own[r]);
       mq[r][j] = ldq(mp + (long)j * sx + own[r]);
+      if (DAMPED) dq[r][j] = ldq(dp + (long)j * sx + own[r]);
     }
   }
 #pragma unroll
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
     const f32x4 *cur = plane[p & 1];
     f32x4 *nxt = plane[(p & 1) ^ 1];
     // loads for D planes ahead (the planes up to x_M + R + D exist in the arrays: D <= R)
-    f32x4 rn[RW], un[RW], mn[RW];
+    f32x4 rn[RW], un[RW], mn[RW], dn[RW];
 #pragma unroll
     for (int q = 0; q < NPT; ++q) aq[q][D - 1] = ldq(u0p + (long)D * sx + poff[q]);
 #pragma unroll
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
       rn[r] = ldq(u0p + (long)(R + D) * sx + own[r]);
       un[r] = ldq(u1p + (long)D * sx + own[r]);
       mn[r] = ldq(mp + (long)D * sx + own[r]);
+      if (DAMPED) dn[r] = ldq(dp + (long)D * sx + own[r]);
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -225,8 +234,17 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
         dzz = dzz + w * (zm + zp);
       }
       const f32x4 mc = mq[r][0];
-      const f32x4 num = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * uq[r][0]) * mc);
-      const f32x4 o = f32x4{num.x / mc.x, num.y / mc.y, num.z / mc.z, num.w / mc.w};
+      f32x4 o;
+      if (DAMPED) {
+        const f32x4 dc = dq[r][0];
+        const f32x4 num =
+            a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * uq[r][0]) * mc + dm.r0 * dc * uc);
+        const f32x4 den = mc + dm.dt * dc;
+        o = f32x4{num.x / den.x, num.y / den.y, num.z / den.z, num.w / den.w};
+      } else {
+        const f32x4 num = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * uq[r][0]) * mc);
+        o = f32x4{num.x / mc.x, num.y / mc.y, num.z / mc.z, num.w / mc.w};
+      }
       if (row_valid[r]) {
         float *dst = u2p + own[r];
         if (nvalid == 4) {
@@ -262,8 +280,14 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
       }
       uq[r][D - 1] = un[r];
       mq[r][D - 1] = mn[r];
+      if (DAMPED) {
+#pragma unroll
+        for (int j = 0; j + 1 < D; ++j) dq[r][j] = dq[r][j + 1];
+        dq[r][D - 1] = dn[r];
+      }
     }
     u0p += sx; u1p += sx; mp += sx; u2p += sx;
+    if (DAMPED) dp += sx;
     __syncthreads();
   }
 }
@@ -278,26 +302,28 @@ int env_int_orders(const char *name, int fallback) {
 }
 
 // Workgroups of the marching sweep that one compute unit holds at a time (registers and LDS decide).
-template <int R, int RW, int D, bool NT>
+template <int R, int RW, int D, bool NT, bool DAMPED>
 int march_workgroups_per_cu() {
   static int n = 0;
   if (n == 0) {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW, D, NT>, 512, 0) != hipSuccess || v < 1) v = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW, D, NT, DAMPED>, 512, 0) != hipSuccess ||
+        v < 1)
+      v = 1;
     n = v;
   }
   return n;
 }
 
-template <int R, int RW, int D, bool NT>
-void launch_order_march(const StencilArgs &a, hipStream_t s) {
+template <int R, int RW, int D, bool NT, bool DAMPED = false>
+void launch_order_march(const StencilArgs &a, hipStream_t s, DampTerm dm = DampTerm{nullptr, 0.0F, 0.0F}) {
   constexpr int TY = 8 * RW;
   const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
   const int nyt = (ey + TY - 1) / TY, nzt = (ez + 255) / 256;
   const long tiles = (long)nyt * nzt;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long slots = (long)cus * march_workgroups_per_cu<R, RW, D, NT>();
+  const long slots = (long)cus * march_workgroups_per_cu<R, RW, D, NT, DAMPED>();
   // x-chunks: the device works through ceil(workgroups / slots) rounds of (chunk length + lead-in), where
   // the lead-in — the 2R planes a chunk loads before its first result, without arithmetic — counts as R
   // planes.  Take the number of chunks that minimises the product.
@@ -316,8 +342,8 @@ void launch_order_march(const StencilArgs &a, hipStream_t s) {
   const int forced = env_int_orders("FDTD_ORDER_XCHUNK", 0);
   const int xchunk = forced > 0 ? forced : (int)((ex + nchunks - 1) / nchunks);
   nchunks = (ex + xchunk - 1) / xchunk;
-  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s, a, xchunk,
-                     nyt, nzt);
+  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT, DAMPED>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s,
+                     a, xchunk, nyt, nzt, dm);
 }
 
 // The marching sweep takes boxes that stay inside the interior of the arrays (its 16-byte accesses reach up
@@ -338,6 +364,13 @@ bool order_march_takes(const StencilArgs &a, int H) {
 }
 
 }  // namespace
+
+// The damped order-4 sweep of fdtd_forward.hip through the marching kernel; -1: not a box the marching sweep takes.
+int fdtd_damped_march(const StencilArgs &a, const float *damp, float dt, float r0, void *stream) {
+  if (!damp || !order_march_takes(a, FDTD_HALO)) return -1;
+  launch_order_march<2, 2, 1, true, true>(a, (hipStream_t)stream, DampTerm{damp, dt, r0});
+  return (int)hipGetLastError();
+}
 
 extern "C" int fdtd_hip_set_space_order(int order) {
   if (!order_supported(order)) return (int)hipErrorInvalidValue;

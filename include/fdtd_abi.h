@@ -143,7 +143,8 @@ int fdtd_hip_get_space_order(void);
  * so there is no reference arithmetic for this entry: parity unpinned.  With damp = 0 the update is the
  * expression of openacc.cpp:159-164; the interpolation is the transpose of the scatter of
  * openacc.cpp:185-196.  Argument conventions of the operator ABI; p_rec_M < p_rec_m: no receivers.
- * Space order 4 only; one-cell-per-thread kernels. */
+ * Space order 4 only.  Boxes of 12 M cells and more take the marching sweep of the space orders with the
+ * damping field as one more streamed operand, smaller ones a one-cell-per-thread kernel: same bits. */
 int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
                        struct dataobj *rec_coords_vec, struct dataobj *src_vec,
                        struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,

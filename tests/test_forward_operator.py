@@ -66,6 +66,24 @@ def test_forward_operator_matches_its_restatement(pkg, hiplib, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [(20, 36, 300), (37, 50, 131)])
+def test_forward_operator_through_the_marching_sweep(pkg, hiplib, monkeypatch, n):
+    """The damped update of large boxes runs through the marching sweep (FDTD_ORDER_MARCH=2 sends these small
+    boxes there, in x-chunks of 16 planes): rows that end inside a z-tile, rows beyond the last y-tile."""
+    monkeypatch.setenv("FDTD_ORDER_MARCH", "2")
+    monkeypatch.setenv("FDTD_ORDER_XCHUNK", "16")
+    nt = 8
+    u, m, src, coords, rec, rcoords, h = random_case(n, nt, 2, 4, 5)
+    damp = sponge(m.shape, 6, 40.0)
+    u_ref, rec_ref = u.copy(), rec.copy()
+    rc, _ = pkg.run_forward(ob.oracle().Oracle_Kernel_Forward, damp, m, rec_ref, rcoords, src, coords, u_ref, h=h)
+    assert rc == 0
+    rc, _ = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h)
+    assert rc == 0
+    assert ob.bits_equal(u, u_ref) and ob.bits_equal(rec, rec_ref)
+
+
+@pytest.mark.gpu
 def test_forward_operator_without_sponge_is_the_reference_update(pkg, hiplib):
     n, nt = (20, 36, 44), 12
     u, m, src, coords, rec, rcoords, h = random_case(n, nt, 2, 3, 4)
