@@ -99,6 +99,12 @@ def lib():
     L.fdtd_hip_receiver_sample.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.fdtd_hip_receiver_sample.restype = C.c_int
+    L.fdtd_hip_stencil_step_damped_order.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                     C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_stencil_step_damped_order.restype = C.c_int
+    L.fdtd_hip_receiver_sample_order.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_receiver_sample_order.restype = C.c_int
     L.fdtd_hip_set_space_order.argtypes = [C.c_int]
     L.fdtd_hip_set_space_order.restype = C.c_int
     L.fdtd_hip_get_space_order.argtypes = []

@@ -64,9 +64,9 @@ int fdtd_inject_level_halo(const struct fdtd_geom *g, const float *m, const floa
 int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
                               float *u2, int order, void *stream);
 
-// fdtd_orders.hip: the order-4 sweep with the damping term of fdtd_forward.hip through the marching kernel;
-// returns -1 without launching anything when the box is not one that kernel takes.
-int fdtd_damped_march(const StencilArgs &a, const float *damp, float dt, float r0, void *stream);
+// fdtd_orders.hip: the same sweep with the damping term of fdtd_forward.hip (damp: padded shape of m).
+int fdtd_stencil_levels_damped(const struct fdtd_geom *g, const float *m, const float *damp, const float *u0,
+                               const float *u1, float *u2, int order, void *stream);
 
 extern "C" int fdtd_hip_get_space_order(void);
 

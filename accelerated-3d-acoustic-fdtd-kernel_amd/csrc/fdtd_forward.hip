@@ -10,8 +10,8 @@
 // (damp = 0: the reference expression), and the receiver interpolation is the transpose of the scatter of
 // openacc.cpp:185-196 (same positions, weights, loop order and bounds test; a corner outside the bounds
 // contributes nothing).  Receivers sample the level the step started from, u(time), as a generated
-// Devito operator does.  The damped update of large boxes runs through the marching sweep of
-// fdtd_orders.hip (same expression, same bits), smaller ones one cell per thread; one receiver per thread.
+// Devito operator does.  The damped update is a variant of the sweeps of fdtd_orders.hip (marching for large
+// boxes, one cell per thread for small ones; every space order); one receiver per thread.
 #include <math.h>
 
 #include <vector>
@@ -23,34 +23,6 @@
 
 namespace {
 
-__constant__ float fw_c_m2 = -8.33333333e-2F, fw_c_m1 = 1.333333330F, fw_c_0 = -2.50F;
-
-struct DampedArgs {
-  StencilArgs s;
-  const float *damp;
-  float dt, r0;
-};
-
-__global__ __launch_bounds__(256) void stencil_damped_kernel(DampedArgs a) {
-  const StencilArgs &s = a.s;
-  const int z = s.z_m + blockIdx.x * 64 + threadIdx.x;
-  const int y = s.y_m + blockIdx.y * 4 + threadIdx.y;
-  const int x = s.x_m + blockIdx.z;
-  if (z > s.z_M || y > s.y_M) return;
-  const long sx = s.sx, sy = s.sy;
-  const long c = (long)(x + FDTD_HALO) * sx + (long)(y + FDTD_HALO) * sy + (z + FDTD_HALO);
-  const float *__restrict__ u0 = s.u0;
-  const float uc = u0[c];
-  const float r5 = fw_c_0 * uc;
-  const float dxx = r5 + fw_c_m2 * (u0[c - 2 * sx] + u0[c + 2 * sx]) + fw_c_m1 * (u0[c - sx] + u0[c + sx]);
-  const float dyy = r5 + fw_c_m2 * (u0[c - 2 * sy] + u0[c + 2 * sy]) + fw_c_m1 * (u0[c - sy] + u0[c + sy]);
-  const float dzz = r5 + fw_c_m2 * (u0[c - 2] + u0[c + 2]) + fw_c_m1 * (u0[c - 1] + u0[c + 1]);
-  const float mc = s.m[c], dc = a.damp[c];
-  const float neg2r1 = -2.0F * s.r1;
-  s.u2[c] = s.dt2 * (s.r2 * dxx + s.r3 * dyy + s.r4 * dzz - (neg2r1 * uc + s.r1 * s.u1[c]) * mc + a.r0 * dc * uc) /
-            (mc + a.dt * dc);
-}
-
 struct ReceiverArgs {
   const float *u, *coords;
   float *rec_row;    // rec + time * rec_stride
@@ -58,6 +30,7 @@ struct ReceiverArgs {
   int x_m, x_M, y_m, y_M, z_m, z_M;
   float h_x, h_y, h_z, o_x, o_y, o_z;
   int p_rec_m, p_rec_M, coord_stride;
+  int halo;          // cells of padding per side of the arrays (the space order)
 };
 
 __global__ __launch_bounds__(256) void receiver_kernel(ReceiverArgs a) {
@@ -75,7 +48,7 @@ __global__ __launch_bounds__(256) void receiver_kernel(ReceiverArgs a) {
         if (rx + posx >= a.x_m - 1 && ry + posy >= a.y_m - 1 && rz + posz >= a.z_m - 1 && rx + posx <= a.x_M + 1 &&
             ry + posy <= a.y_M + 1 && rz + posz <= a.z_M + 1)
           sum += (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) * (rz * pz + (1 - rz) * (1 - pz)) *
-                 a.u[(long)(rx + posx + FDTD_HALO) * a.sx + (long)(ry + posy + FDTD_HALO) * a.sy + (rz + posz + FDTD_HALO)];
+                 a.u[(long)(rx + posx + a.halo) * a.sx + (long)(ry + posy + a.halo) * a.sy + (rz + posz + a.halo)];
   a.rec_row[p] = sum;
 }
 
@@ -94,42 +67,25 @@ struct Buffers {
 
 }  // namespace
 
-// One damped sweep on explicit level pointers (damp has the padded shape of m).
+// One damped sweep of level t0 into level t2 (damp has the padded shape of m), arrays padded by `order` cells.
+extern "C" int fdtd_hip_stencil_step_damped_order(const struct fdtd_geom *g, const float *m, const float *damp, float *u,
+                                                  int t0, int t1, int t2, int order, void *stream) {
+  if (!g || !m || !damp || !u || t0 < 0 || t0 > 2 || t1 < 0 || t1 > 2 || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
+  const long vol = (long)g->nxp * g->nyp * g->nzp;
+  return fdtd_stencil_levels_damped(g, m, damp, u + t0 * vol, u + t1 * vol, u + t2 * vol, order, stream);
+}
 extern "C" int fdtd_hip_stencil_step_damped(const struct fdtd_geom *g, const float *m, const float *damp, float *u,
                                             int t0, int t1, int t2, void *stream) {
-  if (!g || !m || !damp || !u || t0 < 0 || t0 > 2 || t1 < 0 || t1 > 2 || t2 < 0 || t2 > 2) return (int)hipErrorInvalidValue;
-  const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
-  if (ex <= 0 || ey <= 0 || ez <= 0) return 0;
-  if (g->x_m + FDTD_HALO - 2 < 0 || g->x_M + FDTD_HALO + 2 > g->nxp - 1 || g->y_m + FDTD_HALO - 2 < 0 ||
-      g->y_M + FDTD_HALO + 2 > g->nyp - 1 || g->z_m + FDTD_HALO - 2 < 0 || g->z_M + FDTD_HALO + 2 > g->nzp - 1)
-    return (int)hipErrorInvalidValue;
-  const long vol = (long)g->nxp * g->nyp * g->nzp;
-  DampedArgs a;
-  a.s.m = m; a.s.u0 = u + t0 * vol; a.s.u1 = u + t1 * vol; a.s.u2 = u + t2 * vol;
-  a.s.sx = (long)g->nyp * g->nzp; a.s.sy = g->nzp;
-  a.s.nxp = g->nxp; a.s.nyp = g->nyp; a.s.nzp = g->nzp;
-  a.s.x_m = g->x_m; a.s.x_M = g->x_M; a.s.y_m = g->y_m; a.s.y_M = g->y_M; a.s.z_m = g->z_m; a.s.z_M = g->z_M;
-  a.s.dt2 = g->dt * g->dt;
-  a.s.r1 = 1.0F / (g->dt * g->dt);
-  a.s.r2 = 1.0F / (g->h_x * g->h_x);
-  a.s.r3 = 1.0F / (g->h_y * g->h_y);
-  a.s.r4 = 1.0F / (g->h_z * g->h_z);
-  a.damp = damp; a.dt = g->dt; a.r0 = 1.0F / g->dt;
-  // large boxes: the marching sweep (x-ring in registers, plane in LDS), same expression, same bits
-  const int rc = fdtd_damped_march(a.s, damp, a.dt, a.r0, stream);
-  if (rc >= 0) return rc;
-  if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(stencil_damped_kernel, dim3((ez + 63) / 64, (ey + 3) / 4, ex), dim3(64, 4, 1), 0,
-                     (hipStream_t)stream, a);
-  return (int)hipGetLastError();
+  return fdtd_hip_stencil_step_damped_order(g, m, damp, u, t0, t1, t2, FDTD_STENCIL_ORDER, stream);
 }
 
 // rec[time][p] = trilinear interpolation of level t of u at rec_coords[p], p = p_rec_m .. p_rec_M.
-extern "C" int fdtd_hip_receiver_sample(const struct fdtd_geom *g, const float *u, int t, const float *rec_coords,
-                                        float *rec, int time, int p_rec_m, int p_rec_M, int rec_stride,
-                                        int coord_stride, void *stream) {
+extern "C" int fdtd_hip_receiver_sample_order(const struct fdtd_geom *g, const float *u, int t, const float *rec_coords,
+                                              float *rec, int time, int p_rec_m, int p_rec_M, int rec_stride,
+                                              int coord_stride, int order, void *stream) {
   if (p_rec_M < p_rec_m) return 0;
-  if (!g || !u || !rec_coords || !rec || t < 0 || t > 2 || rec_stride < 1 || coord_stride < 3 || time < 0)
+  if (!g || !u || !rec_coords || !rec || t < 0 || t > 2 || rec_stride < 1 || coord_stride < 3 || time < 0 || order < 4 ||
+      order > 12 || order % 2)
     return (int)hipErrorInvalidValue;
   ReceiverArgs a;
   a.u = u + (long)t * g->nxp * g->nyp * g->nzp;
@@ -139,9 +95,16 @@ extern "C" int fdtd_hip_receiver_sample(const struct fdtd_geom *g, const float *
   a.x_m = g->x_m; a.x_M = g->x_M; a.y_m = g->y_m; a.y_M = g->y_M; a.z_m = g->z_m; a.z_M = g->z_M;
   a.h_x = g->h_x; a.h_y = g->h_y; a.h_z = g->h_z; a.o_x = g->o_x; a.o_y = g->o_y; a.o_z = g->o_z;
   a.p_rec_m = p_rec_m; a.p_rec_M = p_rec_M; a.coord_stride = coord_stride;
+  a.halo = order;
   const int n = p_rec_M - p_rec_m + 1;
   hipLaunchKernelGGL(receiver_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+extern "C" int fdtd_hip_receiver_sample(const struct fdtd_geom *g, const float *u, int t, const float *rec_coords,
+                                        float *rec, int time, int p_rec_m, int p_rec_M, int rec_stride,
+                                        int coord_stride, void *stream) {
+  return fdtd_hip_receiver_sample_order(g, u, t, rec_coords, rec, time, p_rec_m, p_rec_M, rec_stride, coord_stride,
+                                        FDTD_STENCIL_ORDER, stream);
 }
 
 // The forward operator of a Devito-style acoustic propagator: damped update, source scatter, receiver
@@ -160,7 +123,7 @@ extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_ve
   if (!damp_vec || !rec_vec || !rec_coords_vec) return (int)hipErrorInvalidValue;
   int rc = fdtd_check_operator_args(m_vec, src_vec, src_coords_vec, u_vec, p_src_M, p_src_m);
   if (rc) return rc;
-  if (fdtd_hip_get_space_order() != FDTD_STENCIL_ORDER) return (int)hipErrorInvalidValue;
+  const int order = fdtd_hip_get_space_order();   // arrays padded by that many cells (main.cpp:32)
   if (!damp_vec->data || !damp_vec->size) return (int)hipErrorInvalidValue;
   for (int d = 0; d < 3; ++d)
     if (damp_vec->size[d] != m_vec->size[d]) return (int)hipErrorInvalidValue;
@@ -223,14 +186,14 @@ extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_ve
     const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3, t2 = (((time + 1) % 3) + 3) % 3;
     const int k = (n_timed > 0 && time >= first_timed) ? time - first_timed : -1;
     if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3], s));
-    if ((rc = fdtd_hip_stencil_step_damped(&g, d_m, d_damp, d_u, t0, t1, t2, s))) return rc;
+    if ((rc = fdtd_hip_stencil_step_damped_order(&g, d_m, d_damp, d_u, t0, t1, t2, order, s))) return rc;
     if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 1], s));
     if (has_src &&
-        (rc = fdtd_hip_source_inject(&g, d_m, d_src, d_sc, d_u, t2, time, p_src_m, p_src_M, src_vec->size[1],
-                                     src_coords_vec->size[1], s)))
+        (rc = fdtd_hip_source_inject_order(&g, d_m, d_src, d_sc, d_u, t2, time, p_src_m, p_src_M, src_vec->size[1],
+                                           src_coords_vec->size[1], order, s)))
       return rc;
-    if (has_rec && (rc = fdtd_hip_receiver_sample(&g, d_u, t0, d_rc, d_rec, time, p_rec_m, p_rec_M, rec_vec->size[1],
-                                                  rec_coords_vec->size[1], s)))
+    if (has_rec && (rc = fdtd_hip_receiver_sample_order(&g, d_u, t0, d_rc, d_rec, time, p_rec_m, p_rec_M, rec_vec->size[1],
+                                                        rec_coords_vec->size[1], order, s)))
       return rc;
     if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 2], s));
   }

@@ -44,8 +44,15 @@ template <> struct Weights<6> {
                                          -8.92857143e-3F, 1.03896104e-3F, -6.01250601e-5F};
 };
 
-template <int R>
-__global__ __launch_bounds__(256) void stencil_order_kernel(StencilArgs a) {
+// DAMPED: the update with an absorbing sponge of fdtd_forward.hip (damping field of the shape of m):
+//     u+ = dt^2 ( lap - (-2 r1 u + r1 u-) m + r0 damp u ) / (m + dt damp)
+struct DampTerm {
+  const float *damp;
+  float dt, r0;   // r0 = 1 / dt
+};
+
+template <int R, bool DAMPED = false>
+__global__ __launch_bounds__(256) void stencil_order_kernel(StencilArgs a, DampTerm dm) {
   constexpr int H = 2 * R;   // padding = space order
   const int z = a.z_m + blockIdx.x * 64 + threadIdx.x;
   const int y = a.y_m + blockIdx.y * 4 + threadIdx.y;
@@ -65,7 +72,13 @@ __global__ __launch_bounds__(256) void stencil_order_kernel(StencilArgs a) {
   }
   const float mc = a.m[c];
   const float neg2r1 = -2.0F * a.r1;
-  a.u2[c] = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * a.u1[c]) * mc) / mc;
+  if (DAMPED) {
+    const float dc = dm.damp[c];
+    a.u2[c] = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * a.u1[c]) * mc + dm.r0 * dc * uc) /
+              (mc + dm.dt * dc);
+  } else {
+    a.u2[c] = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * a.u1[c]) * mc) / mc;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -93,11 +106,6 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {   // workgro
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-// DAMPED: the update with an absorbing sponge of fdtd_forward.hip (damping field of the shape of m).
-struct DampTerm {
-  const float *damp;
-  float dt, r0;   // r0 = 1 / dt
-};
 template <int R, int RW, int D, bool NT, bool DAMPED = false>
 __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a, int xchunk, int nyt, int nzt,
                                                                   DampTerm dm) {
@@ -365,13 +373,6 @@ bool order_march_takes(const StencilArgs &a, int H) {
 
 }  // namespace
 
-// The damped order-4 sweep of fdtd_forward.hip through the marching kernel; -1: not a box the marching sweep takes.
-int fdtd_damped_march(const StencilArgs &a, const float *damp, float dt, float r0, void *stream) {
-  if (!damp || !order_march_takes(a, FDTD_HALO)) return -1;
-  launch_order_march<2, 2, 1, true, true>(a, (hipStream_t)stream, DampTerm{damp, dt, r0});
-  return (int)hipGetLastError();
-}
-
 extern "C" int fdtd_hip_set_space_order(int order) {
   if (!order_supported(order)) return (int)hipErrorInvalidValue;
   g_space_order = order;
@@ -387,8 +388,9 @@ extern "C" int fdtd_hip_get_space_order(void) {
   return g_space_order;
 }
 
-int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
-                              float *u2, int order, void *stream) {
+// One sweep of any supported order; damp != nullptr: with the damping term.
+static int sweep_order(const struct fdtd_geom *g, const float *m, const float *damp, const float *u0, const float *u1,
+                       float *u2, int order, void *stream) {
   if (!g || !m || !u0 || !u1 || !u2 || !order_supported(order)) return (int)hipErrorInvalidValue;
   const int R = order / 2, H = order;
   const int ex = g->x_M - g->x_m + 1, ey = g->y_M - g->y_m + 1, ez = g->z_M - g->z_m + 1;
@@ -407,15 +409,17 @@ int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const f
   a.r2 = 1.0F / (g->h_x * g->h_x);
   a.r3 = 1.0F / (g->h_y * g->h_y);
   a.r4 = 1.0F / (g->h_z * g->h_z);
+  const DampTerm dm{damp, g->dt, 1.0F / g->dt};
   hipStream_t s = (hipStream_t)stream;
   if (order_march_takes(a, H)) {
     // non-temporal stores: the level written is not read again before the next sweep has streamed the
     // whole field through the caches (FDTD_ORDER_NT = 0 keeps plain stores, for measurements)
     const int nt = env_int_orders("FDTD_ORDER_NT", 1);
-#define ORDER_MARCH(R_)                                          \
-  case R_:                                                       \
-    if (nt) launch_order_march<R_, 2, 1, true>(a, s);            \
-    else launch_order_march<R_, 2, 1, false>(a, s);              \
+#define ORDER_MARCH(R_)                                                    \
+  case R_:                                                                 \
+    if (damp) launch_order_march<R_, 2, 1, true, true>(a, s, dm);          \
+    else if (nt) launch_order_march<R_, 2, 1, true>(a, s);                 \
+    else launch_order_march<R_, 2, 1, false>(a, s);                        \
     break;
     switch (R) {
       ORDER_MARCH(2)
@@ -430,14 +434,32 @@ int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const f
   }
   if (ex > 65535 || (ey + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
   const dim3 grid((ez + 63) / 64, (ey + 3) / 4, ex), block(64, 4, 1);
+#define ORDER_CELL(R_)                                                                           \
+  case R_:                                                                                       \
+    if (damp) hipLaunchKernelGGL((stencil_order_kernel<R_, true>), grid, block, 0, s, a, dm);    \
+    else hipLaunchKernelGGL((stencil_order_kernel<R_, false>), grid, block, 0, s, a, dm);        \
+    break;
   switch (R) {
-    case 2: hipLaunchKernelGGL(stencil_order_kernel<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(stencil_order_kernel<3>, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(stencil_order_kernel<4>, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(stencil_order_kernel<5>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(stencil_order_kernel<6>, grid, block, 0, s, a); break;
+    ORDER_CELL(2)
+    ORDER_CELL(3)
+    ORDER_CELL(4)
+    ORDER_CELL(5)
+    default:
+    ORDER_CELL(6)
   }
+#undef ORDER_CELL
   return (int)hipGetLastError();
+}
+
+int fdtd_stencil_levels_order(const struct fdtd_geom *g, const float *m, const float *u0, const float *u1,
+                              float *u2, int order, void *stream) {
+  return sweep_order(g, m, nullptr, u0, u1, u2, order, stream);
+}
+
+int fdtd_stencil_levels_damped(const struct fdtd_geom *g, const float *m, const float *damp, const float *u0,
+                               const float *u1, float *u2, int order, void *stream) {
+  if (!damp) return (int)hipErrorInvalidValue;
+  return sweep_order(g, m, damp, u0, u1, u2, order, stream);
 }
 
 extern "C" int fdtd_hip_stencil_step_order(const struct fdtd_geom *g, const float *m, float *u, int t0, int t1,

@@ -143,8 +143,9 @@ int fdtd_hip_get_space_order(void);
  * so there is no reference arithmetic for this entry: parity unpinned.  With damp = 0 the update is the
  * expression of openacc.cpp:159-164; the interpolation is the transpose of the scatter of
  * openacc.cpp:185-196.  Argument conventions of the operator ABI; p_rec_M < p_rec_m: no receivers.
- * Space order 4 only.  Boxes of 12 M cells and more take the marching sweep of the space orders with the
- * damping field as one more streamed operand, smaller ones a one-cell-per-thread kernel: same bits. */
+ * Every space order (fdtd_hip_set_space_order).  Boxes of 12 M cells and more take the marching sweep of the
+ * space orders with the damping field as one more streamed operand, smaller ones a one-cell-per-thread
+ * kernel: same bits. */
 int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
                        struct dataobj *rec_coords_vec, struct dataobj *src_vec,
                        struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,
@@ -197,12 +198,19 @@ int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const float *m, cons
                                  int p_src_M, int src_stride, int coord_stride, int order, void *stream);
 
 /* The two device kernels Kernel_HIP_Forward adds to the path, on device arrays: one damped sweep, and
- * the receiver interpolation of level t of u into rec[time][p_rec_m..p_rec_M]. */
+ * the receiver interpolation of level t of u into rec[time][p_rec_m..p_rec_M].  The _order forms take
+ * the space order (arrays padded by that many cells); the plain forms are order 4. */
 int fdtd_hip_stencil_step_damped(const struct fdtd_geom *g, const float *m, const float *damp, float *u,
                                  int t0, int t1, int t2, void *stream);
+int fdtd_hip_stencil_step_damped_order(const struct fdtd_geom *g, const float *m, const float *damp,
+                                       float *u, int t0, int t1, int t2, int order, void *stream);
 int fdtd_hip_receiver_sample(const struct fdtd_geom *g, const float *u, int t, const float *rec_coords,
                              float *rec, int time, int p_rec_m, int p_rec_M, int rec_stride,
                              int coord_stride, void *stream);
+int fdtd_hip_receiver_sample_order(const struct fdtd_geom *g, const float *u, int t,
+                                   const float *rec_coords, float *rec, int time, int p_rec_m,
+                                   int p_rec_M, int rec_stride, int coord_stride, int order,
+                                   void *stream);
 
 /* One leapfrog update  u[t2] <- stencil(u[t0], u[t1], m)  over the ranges in g.
  * Replaces one launch of stencil_update_kernel_1step (cuda.cu:237-243) /

@@ -443,3 +443,77 @@ int Oracle_Kernel_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struc
   }
   return 0;
 }
+
+/* The same operator for space order 4 .. 12 on arrays padded by `order` cells per side: the generic
+ * sweep of oracle_section0_order with the damping term, the scatter and the receivers on the wider
+ * padding.  With order 4 it gives the bits of Oracle_Kernel_Forward (checked by the tests). */
+int Oracle_Kernel_ForwardOrder(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
+                               struct dataobj *rec_coords_vec, struct dataobj *src_vec,
+                               struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,
+                               const int x_m, const int y_M, const int y_m, const int z_M,
+                               const int z_m, const float dt, const float h_x, const float h_y,
+                               const float h_z, const float o_x, const float o_y, const float o_z,
+                               const int p_rec_M, const int p_rec_m, const int p_src_M,
+                               const int p_src_m, const int time_M, const int time_m,
+                               const int deviceid, const int devicerm, struct profiler *timers,
+                               int order) {
+  (void)deviceid; (void)devicerm; (void)timers;
+  if (order < 4 || order > 12 || order % 2) return 1;
+  const int R = order / 2, H = order;
+  const float *w = k_order_weights[R - 2];
+  const long nxp = u_vec->size[1], nyp = u_vec->size[2], nzp = u_vec->size[3];
+  const long vol = nxp * nyp * nzp, sx = nyp * nzp, sy = nzp;
+  float *u = (float *)u_vec->data;
+  const float *m = (const float *)m_vec->data, *damp = (const float *)damp_vec->data;
+  const float *src = (const float *)src_vec->data, *scoords = (const float *)src_coords_vec->data;
+  float *rec = (float *)rec_vec->data;
+  const float *rcoords = (const float *)rec_coords_vec->data;
+  const float r0 = 1.0F / dt, r1 = 1.0F / (dt * dt), r2 = 1.0F / (h_x * h_x), r3 = 1.0F / (h_y * h_y),
+              r4 = 1.0F / (h_z * h_z);
+  const int has_src = (src_vec->size[0] * src_vec->size[1] > 0 && p_src_M - p_src_m + 1 > 0);
+  for (int time = time_m; time <= time_M; time += 1) {
+    const int t0 = time % 3, t1 = (time + 2) % 3, t2 = (time + 1) % 3;
+    const float *u0 = u + t0 * vol, *u1 = u + t1 * vol;
+    float *u2 = u + t2 * vol;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int x = x_m; x <= x_M; x += 1)
+      for (int y = y_m; y <= y_M; y += 1)
+        for (int z = z_m; z <= z_M; z += 1) {
+          const long c = (long)(x + H) * sx + (long)(y + H) * sy + (z + H);
+          const float uc = u0[c];
+          const float r5 = w[0] * uc;
+          float dxx = r5, dyy = r5, dzz = r5;
+          for (int k = R; k >= 1; --k) {
+            dxx = dxx + w[k] * (u0[c - k * sx] + u0[c + k * sx]);
+            dyy = dyy + w[k] * (u0[c - k * sy] + u0[c + k * sy]);
+            dzz = dzz + w[k] * (u0[c - k] + u0[c + k]);
+          }
+          const float mc = m[c], dc = damp[c];
+          u2[c] = dt * dt *
+                  (r2 * dxx + r3 * dyy + r4 * dzz - (-2.0F * r1 * uc + r1 * u1[c]) * mc + r0 * dc * uc) /
+                  (mc + dt * dc);
+        }
+    if (has_src)
+      oracle_section1_order(H, m, src, scoords, u2, nyp, nzp, x_m, x_M, y_m, y_M, z_m, z_M, h_x, h_y,
+                            h_z, o_x, o_y, o_z, p_src_m, p_src_M, time, src_vec->size[1],
+                            src_coords_vec->size[1]);
+    for (int p = p_rec_m; p <= p_rec_M; p += 1) {
+      const long cs = rec_coords_vec->size[1];
+      const float gx = (-o_x + rcoords[p * cs + 0]) / h_x, gy = (-o_y + rcoords[p * cs + 1]) / h_y,
+                  gz = (-o_z + rcoords[p * cs + 2]) / h_z;
+      const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
+      const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
+      float sum = 0.0F;
+      for (int rx = 0; rx <= 1; rx += 1)
+        for (int ry = 0; ry <= 1; ry += 1)
+          for (int rz = 0; rz <= 1; rz += 1)
+            if (rx + posx >= x_m - 1 && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
+                rx + posx <= x_M + 1 && ry + posy <= y_M + 1 && rz + posz <= z_M + 1)
+              sum += (rx * px + (1 - rx) * (1 - px)) * (ry * py + (1 - ry) * (1 - py)) *
+                     (rz * pz + (1 - rz) * (1 - pz)) *
+                     u0[(long)(rx + posx + H) * sx + (long)(ry + posy + H) * sy + (rz + posz + H)];
+      rec[(long)time * rec_vec->size[1] + p] = sum;
+    }
+  }
+  return 0;
+}

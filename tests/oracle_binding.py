@@ -43,6 +43,8 @@ def oracle():
         L.Oracle_Kernel_SpaceOrder.restype = C.c_int
         L.Oracle_Kernel_Forward.argtypes = pkg.abi.FORWARD_ARGTYPES
         L.Oracle_Kernel_Forward.restype = C.c_int
+        L.Oracle_Kernel_ForwardOrder.argtypes = pkg.abi.FORWARD_ARGTYPES + [C.c_int]
+        L.Oracle_Kernel_ForwardOrder.restype = C.c_int
         L.oracle_compare_fields.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.POINTER(pkg.Parity)]
         L.oracle_compare_fields.restype = None
@@ -85,6 +87,15 @@ def run_oracle_order(order, m, src, coords, u, **kw):
     rc, prof = pkg.run_operator(call, m, src, coords, u, **kw)
     assert rc == 0
     return prof
+
+
+def forward_oracle_order(order):
+    """Oracle_Kernel_ForwardOrder with the order bound: a callable with the argument list of Kernel_HIP_Forward."""
+    fn = oracle().Oracle_Kernel_ForwardOrder
+
+    def call(*args):
+        return fn(*args, order)
+    return call
 
 
 def run_ref(m, src, coords, u, **kw):

@@ -10,25 +10,25 @@ import pytest
 import oracle_binding as ob
 
 
-def sponge(shape, nbl, peak):
+def sponge(shape, nbl, peak, halo=4):
     """Quadratic ramp over the outer nbl interior cells of every face (0 in the middle), padded shape."""
     d = np.zeros(shape, dtype=np.float32)
     for ax in range(3):
-        n = shape[ax] - 8
+        n = shape[ax] - 2 * halo
         i = np.arange(n)
         dist = np.minimum(i, n - 1 - i)
         ramp = np.where(dist < nbl, ((nbl - dist) / nbl) ** 2, 0.0) * peak
         full = np.zeros(shape[ax])
-        full[4:-4] = ramp
+        full[halo:-halo] = ramp
         sh = [1, 1, 1]
         sh[ax] = shape[ax]
         d = np.maximum(d, full.reshape(sh).astype(np.float32))
     return np.ascontiguousarray(np.broadcast_to(d, shape), dtype=np.float32)
 
 
-def random_case(n, nt, nsrc, nrec, seed):
+def random_case(n, nt, nsrc, nrec, seed, halo=4):
     rng = np.random.default_rng(seed)
-    shape = tuple(v + 8 for v in n)
+    shape = tuple(v + 2 * halo for v in n)
     u = np.zeros((3,) + shape, dtype=np.float32)
     u[0] = rng.uniform(-1, 1, size=shape).astype(np.float32)
     u[1] = rng.uniform(-1, 1, size=shape).astype(np.float32)
@@ -81,6 +81,41 @@ def test_forward_operator_through_the_marching_sweep(pkg, hiplib, monkeypatch, n
     rc, _ = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h)
     assert rc == 0
     assert ob.bits_equal(u, u_ref) and ob.bits_equal(rec, rec_ref)
+
+
+def test_generic_restatement_at_order_4_is_the_order_4_restatement(pkg):
+    """CPU: Oracle_Kernel_ForwardOrder(order = 4) gives the bits of Oracle_Kernel_Forward."""
+    n, nt = (14, 12, 20), 9
+    u, m, src, coords, rec, rcoords, h = random_case(n, nt, 2, 4, 11)
+    damp = sponge(m.shape, 4, 40.0)
+    u_a, rec_a, u_b, rec_b = u.copy(), rec.copy(), u.copy(), rec.copy()
+    assert pkg.run_forward(ob.oracle().Oracle_Kernel_Forward, damp, m, rec_a, rcoords, src, coords, u_a, h=h)[0] == 0
+    assert pkg.run_forward(ob.forward_oracle_order(4), damp, m, rec_b, rcoords, src, coords, u_b, h=h)[0] == 0
+    assert ob.bits_equal(u_a, u_b) and ob.bits_equal(rec_a, rec_b)
+    assert pkg.run_forward(ob.forward_oracle_order(5), damp, m, rec_b, rcoords, src, coords, u_b, h=h)[0] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [6, 8, 12])
+@pytest.mark.parametrize("march", [False, True])
+def test_forward_operator_at_space_orders(pkg, hiplib, monkeypatch, order, march):
+    """Sponge, sources and receivers on arrays padded by the space order, through the one-cell-per-thread sweep
+    and through the marching sweep, against the generic restatement."""
+    monkeypatch.setenv("FDTD_ORDER_MARCH", "2" if march else "0")
+    monkeypatch.setenv("FDTD_ORDER_XCHUNK", "16")
+    n, nt = (24, 30, 140), 8
+    u, m, src, coords, rec, rcoords, h = random_case(n, nt, 2, 4, 20 + order, halo=order)
+    damp = sponge(m.shape, 6, 40.0, halo=order)
+    b = (0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1)
+    u_ref, rec_ref = u.copy(), rec.copy()
+    assert pkg.run_forward(ob.forward_oracle_order(order), damp, m, rec_ref, rcoords, src, coords, u_ref, h=h, bounds=b)[0] == 0
+    assert hiplib.fdtd_hip_set_space_order(order) == 0
+    try:
+        rc, _ = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h, bounds=b)
+    finally:
+        assert hiplib.fdtd_hip_set_space_order(4) == 0
+    assert rc == 0
+    assert ob.bits_equal(u, u_ref) and ob.bits_equal(rec, rec_ref) and np.isfinite(rec).all()
 
 
 @pytest.mark.gpu
