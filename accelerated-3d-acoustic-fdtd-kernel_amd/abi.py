@@ -297,9 +297,10 @@ def fill_correctness_inputs(n):
     return u, m
 
 
-def standard_inputs(nx, ny, nz, nt, nsrc=1):
-    """Inputs of the driver's benchmark run (main.cpp:345-356): u=0, m=1.5, Ricker sources."""
-    shape = (nx + 2 * HALO, ny + 2 * HALO, nz + 2 * HALO)
+def standard_inputs(nx, ny, nz, nt, nsrc=1, halo=HALO):
+    """Inputs of the driver's benchmark run (main.cpp:345-356): u=0, m=1.5, Ricker sources; `halo` cells of
+    padding per side (HALO = STENCIL_ORDER, main.cpp:32)."""
+    shape = (nx + 2 * halo, ny + 2 * halo, nz + 2 * halo)
     u = np.zeros((3,) + shape, dtype=np.float32)
     m = np.full(shape, 1.5, dtype=np.float32)
     src = fill_ricker(nt, nsrc)

@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--velocity", default="constant", choices=["constant", "layered"],
                     help="N=1: m = 1.5 everywhere (the reference's benchmark input, main.cpp:352) or five horizontal "
                          "layers of velocity 1.5 .. 4.5 (m = 1/v^2): same kernels, heterogeneous medium")
+    ap.add_argument("--space-order", type=int, default=4, choices=[4, 6, 8, 10, 12],
+                    help="space order of the stencil (main.cpp:27-32: arrays padded by that many cells); N = 1 only, "
+                         "orders above 4 run one step per sweep through the library's time loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="oracle steps for the CPU baseline sample")
     return ap.parse_args()
@@ -324,7 +327,12 @@ def main():
         dist.destroy_process_group()
     else:
         ranks_seen = 1
-        u, m, src, coords = pkg.standard_inputs(n, n, n, total_steps, 1)
+        order = args.space_order
+        if order != 4:
+            if h16 or args.variant != "auto":
+                raise SystemExit("bench.py: --space-order above 4 goes with fp32 storage and --variant auto")
+            assert L.fdtd_hip_set_space_order(order) == 0
+        u, m, src, coords = pkg.standard_inputs(n, n, n, total_steps, 1, halo=order)
         if args.velocity == "layered":
             v = 1.5 + 0.75 * np.minimum(4, (np.arange(m.shape[2]) * 5) // m.shape[2])
             m[:] = (1.0 / (v * v)).astype(np.float32)[None, None, :]
@@ -333,7 +341,7 @@ def main():
         s_d = torch.from_numpy(src).to(dev)
         c_d = torch.from_numpy(coords).to(dev)
         del u, m
-        npad = n + 2 * pkg.HALO
+        npad = n + 2 * order
         g = pkg.Geom(npad, npad, npad, 0, n - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
         stream = torch.cuda.current_stream()
         sh = C.c_void_p(stream.cuda_stream)
@@ -350,7 +358,7 @@ def main():
             return fn(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), u_d.data_ptr(), t2, t, 0, 0, 1, 3, sh)
 
         # two steps per sweep where the library takes the fused sweep for this box
-        fused = (not h16) and K >= 2 and bool(L.fdtd_hip_two_steps_fuses(C.byref(g), 1, variant))
+        fused = (not h16) and order == 4 and K >= 2 and bool(L.fdtd_hip_two_steps_fuses(C.byref(g), 1, variant))
         updates_per_launch = 2 if fused else 1
         use_events = os.environ.get("FDTD_BENCH_EVENTS", "1") != "0"
         if fused:
@@ -504,7 +512,8 @@ def main():
         except Exception:
             pass
     if not slabs:
-        wl = (f"{n}^3 fp32 acoustic FDTD, 4th-order star + leapfrog + 1 Ricker source, "
+        so = args.space_order
+        wl = (f"{n}^3 fp32 acoustic FDTD, {so}th-order star + leapfrog + 1 Ricker source, "
               f"{total_steps} steps ({W} untimed)"
               + (", five velocity layers 1.5 .. 4.5" if args.velocity == "layered" else ""))
     else:
@@ -550,7 +559,7 @@ def main():
         out["exchange"] = exchange
     if slabs and world == 1:
         out["config"]["workload"] += " [one rank, own neighbour on both sides: schedule rehearsal]"
-    if world == 1 and not slabs and not args.no_cpu_baseline:
+    if world == 1 and not slabs and not args.no_cpu_baseline and args.space_order == 4:
         out["cpu_baseline"] = cpu_baseline(pkg, n, args.cpu_steps)
     print(json.dumps(out))
 

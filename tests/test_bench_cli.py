@@ -47,3 +47,14 @@ def test_bench_single_gpu_line():
     assert out["n_gpus"] == 1 and out["reps"]["n"] == 3 and len(out["reps"]["Mcells_per_s"]) == 3
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"]
     assert out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["one_thread"]["cores"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_at_a_higher_space_order():
+    """--space-order 8: arrays padded by 8 cells, one step per sweep through the library's time loop."""
+    r = subprocess.run([sys.executable, BENCH, "--grid", "256", "--steps", "10", "--warmup", "5", "--reps", "2",
+                        "--space-order", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "8th-order" in out["config"]["workload"] and out["value"] > 0 and "cpu_baseline" not in out
+    assert out["roofline"]["cell_updates_per_launch"] == 256 ** 3
