@@ -167,3 +167,41 @@ def test_space_orders_and_forward_operator_on_random_boxes(pkg, hiplib, monkeypa
     finally:
         assert hiplib.fdtd_hip_set_space_order(4) == 0
     assert ob.bits_equal(u, u_ref), (seed, order, march, forward, n, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDTD_FUZZ_SEEDS", "16"))))
+def test_fp16_storage_on_random_boxes(pkg, hiplib, monkeypatch, seed):
+    """Kernel_HIP_FP16Storage (binary16 wavefield in memory, fp32 arithmetic) on random whole boxes, through the
+    marching kernel or the one-cell-per-thread kernel, bit for bit against the oracle stepped with a
+    round-to-binary16 after every store (inputs pre-rounded so that the upload is lossless)."""
+    rng = np.random.default_rng(13000 + seed)
+    monkeypatch.setenv("FDTD_MARCH_MIN_CELLS", "0" if rng.integers(0, 2) else "2000000000")
+    nz = [int(rng.integers(5, 70)), 8 * int(rng.integers(4, 40)), 4 * int(rng.integers(30, 80))][int(rng.integers(0, 3))]
+    n = (int(rng.integers(5, 30)), int(rng.integers(5, 40)), nz)
+    shape = tuple(v + 8 for v in n)
+    u = np.zeros((3,) + shape, dtype=np.float32)
+    u[0] = rng.uniform(-1, 1, size=shape)
+    u[2] = u[0] + rng.uniform(-0.01, 0.01, size=shape)
+    u = u.astype(np.float16).astype(np.float32)
+    m = rng.uniform(0.5, 3, size=shape).astype(np.float32)
+    h = tuple(float(v) for v in rng.uniform(0.5, 2.0, size=3).astype(np.float32))
+    nsrc = [0, 1, 5][int(rng.integers(0, 3))]
+    nt = int(rng.integers(6, 12))
+    src = coords = None
+    if nsrc:
+        src = rng.uniform(-50, 50, size=(nt, nsrc)).astype(np.float32)
+        coords = (rng.uniform(0.0, 1.0, size=(nsrc, 3)) * (np.array(n) - 1) * np.array(h)).astype(np.float32)
+    ue = u.copy()
+    bounds = (0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1)
+    hh = tuple(np.float32(v) for v in h)
+    for t in range(nt):
+        t0, t1, t2 = t % 3, (t + 2) % 3, (t + 1) % 3
+        ob.oracle_stencil_step(m, ue, bounds, np.float32(1e-3), hh, t0, t1, t2)
+        ue[t2] = ue[t2].astype(np.float16).astype(np.float32)
+        if nsrc:
+            ob.oracle_source_inject(m, src, coords, ue, bounds, hh, (0.0, 0.0, 0.0), (0, nsrc - 1), t, t2)
+            ue[t2] = ue[t2].astype(np.float16).astype(np.float32)
+    rc, _ = pkg.run_operator(hiplib.Kernel_HIP_FP16Storage, m, src, coords, u, h=h, time_M=nt - 1)
+    assert rc == 0
+    assert ob.bits_equal(u, ue), (seed, n, nsrc)
