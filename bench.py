@@ -6,12 +6,12 @@
 One "step" is one time step of the propagator (section0 stencil sweep + section1 source
 scatter, reference openacc.cpp:148-205) on fields that are already resident in HBM.
 
-N = 1 runs BASELINE.json's headline configuration: 512^3 fp32, one Ricker source, the kernels of
+N = 1 runs the headline configuration of the benchmark: 512^3 fp32, one Ricker source, the kernels of
 Kernel_CUDA_Optimized.  With the defaults W = 5 and K = 45 the timed window is steps 5..49 of a
 50-step run, i.e. exactly the reference's timer window (openacc.cpp:5,148).
 
 N > 1 runs the slab-decomposed propagator, one rank per GPU, ghost planes exchanged with the two
-neighbours as RCCL point-to-point messages.  Default: BASELINE.json's multi-GPU configuration, a
+neighbours as RCCL point-to-point messages.  Default: the multi-GPU configuration of the benchmark, a
 2048^3 grid split into N x-slabs (strong scaling); --weak gives every rank --grid planes instead.
 `python bench.py --gpus N` starts its own N ranks (child processes, started before this process
 touches the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it
@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
 ALGO_BYTES_PER_UPDATE = 16.0    # fp32: read u[t0], u[t1], m; write u[t2]; 4 B each
 ALGO_BYTES_PER_UPDATE_F16 = 10.0  # fp16 storage: u levels 2 B each, m stays 4 B
-MULTI_GPU_GRID = 2048           # BASELINE.json configs[4]: 2048^3 across the GPUs of a node
+MULTI_GPU_GRID = 2048           # the multi-GPU configuration: 2048^3 across the GPUs of a node
 
 
 def parse_args():
