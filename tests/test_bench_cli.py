@@ -38,6 +38,28 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_under_the_distributed_launcher():
+    """The other way a driver starts N ranks: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    (both ranks on the one GPU, ghosts over gloo); rank 0 prints the one line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, FDTD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--grid", "512",
+                        "--global-x", "96", "--steps", "4", "--warmup", "2", "--reps", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and "96x512x512" in out["config"]["workload"]
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line():
     """The N = 1 line at a reduced size: repetitions, roofline and CPU baseline objects are present."""
     r = subprocess.run([sys.executable, BENCH, "--grid", "256", "--steps", "10", "--warmup", "5", "--reps", "3",
