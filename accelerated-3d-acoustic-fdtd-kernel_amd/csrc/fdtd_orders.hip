@@ -106,21 +106,27 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {   // workgro
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-template <int R, int RW, int D, bool NT, bool DAMPED = false>
+// LPR = lanes per row: 64 (tiles of 256 cells) or 32 (tiles of 128 cells: a wave then carries two rows per
+// row slot and the tile has twice as many rows), for rows that fill multiples of 128 cells better.
+template <int R, int RW, int D, bool NT, bool DAMPED = false, int LPR = 64>
 __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a, int xchunk, int nyt, int nzt,
                                                                   DampTerm dm) {
   static_assert(D >= 1 && D <= R, "planes up to x_M + R + D must exist");
-  constexpr int H = 2 * R, TY = 8 * RW, NROWS = TY + 2 * R;
+  static_assert(LPR == 64 || LPR == 32, "whole or half waves per row");
+  constexpr int RPS = 64 / LPR;               // rows per row slot of a wave
+  constexpr int TZ = 4 * LPR;                 // cells of a tile row
+  constexpr int H = 2 * R, TY = 8 * RW * RPS, NROWS = TY + 2 * R;
   constexpr int ZF = R > 4 ? 2 : 1;           // float4s beyond the tile per side
-  constexpr int ROWF4 = 64 + 2 * ZF;
-  constexpr int NPIECE = 2 * R * 64 + TY * 2 * ZF;   // float4s around the tile, per plane
-  constexpr int NPT = (NPIECE + 511) / 512;            // ... per thread
+  constexpr int ROWF4 = LPR + 2 * ZF;
+  constexpr int NPIECE = 2 * R * LPR + TY * 2 * ZF;   // float4s around the tile, per plane
+  constexpr int NPT = (NPIECE + 511) / 512;             // ... per thread
   __shared__ f32x4 plane[2][NROWS * ROWF4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane % LPR, sub = lane / LPR;   // float4 of the row, row of the row slot
   const int t = xcd_contiguous(blockIdx.x, gridDim.x);
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nzt * nyt);
-  const int zb = a.z_m + zt * 256, yb = a.y_m + yt * TY;
+  const int zb = a.z_m + zt * TZ, yb = a.y_m + yt * TY;
   const int x_begin = a.x_m + xc * xchunk, x_end = min(x_begin + xchunk - 1, a.x_M);
   if (x_begin > x_end) return;
   const int sy = (int)a.sy;
@@ -130,13 +136,13 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   auto yaddr = [&](int y) { return min(y, a.y_M + R) + H; };
 
   // own cells
-  const int z0 = zb + 4 * lane;
+  const int z0 = zb + 4 * col;
   const int nvalid = min(max(a.z_M + 1 - z0, 0), 4);
   int own[RW];          // offset inside a plane
   bool row_valid[RW];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
-    const int y = yb + wave * RW + r;
+    const int y = yb + (wave * RW + r) * RPS + sub;
     row_valid[r] = y <= a.y_M;
     own[r] = yaddr(y) * sy + zaddr(z0);
   }
@@ -148,16 +154,16 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
     const int i = (int)threadIdx.x + 512 * q;
     pvalid[q] = i < NPIECE;
     int y, z, slot;
-    if (i < 2 * R * 64) {            // rows below and above the tile
-      const int hr = i >> 6, col = i & 63;
+    if (i < 2 * R * LPR) {           // rows below and above the tile
+      const int hr = i / LPR, c = i % LPR;
       y = hr < R ? yb - R + hr : yb + TY + (hr - R);
-      z = zb + 4 * col;
-      slot = (hr < R ? hr : TY + hr) * ROWF4 + ZF + col;
+      z = zb + 4 * c;
+      slot = (hr < R ? hr : TY + hr) * ROWF4 + ZF + c;
     } else {                         // cells before and behind the tile, own rows
-      const int j = i - 2 * R * 64, row = (j / (2 * ZF)) % TY, k = j % (2 * ZF);
+      const int j = i - 2 * R * LPR, row = (j / (2 * ZF)) % TY, k = j % (2 * ZF);
       y = yb + row;
-      z = k < ZF ? zb - 4 * ZF + 4 * k : zb + 256 + 4 * (k - ZF);
-      slot = (R + row) * ROWF4 + (k < ZF ? k : 64 + k);
+      z = k < ZF ? zb - 4 * ZF + 4 * k : zb + TZ + 4 * (k - ZF);
+      slot = (R + row) * ROWF4 + (k < ZF ? k : LPR + k);
     }
     poff[q] = yaddr(y) * sy + zaddr(z);
     pslot[q] = slot;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   {
     f32x4 *buf = plane[x_begin & 1];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) buf[(R + wave * RW + r) * ROWF4 + ZF + lane] = ring[r][R];
+    for (int r = 0; r < RW; ++r) buf[(R + (wave * RW + r) * RPS + sub) * ROWF4 + ZF + col] = ring[r][R];
 #pragma unroll
     for (int q = 0; q < NPT; ++q)
       if (pvalid[q]) buf[pslot[q]] = ldq(u0p + poff[q]);
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const int row = R + wave * RW + r;
+      const int row = R + (wave * RW + r) * RPS + sub;
       const f32x4 uc = ring[r][R];
       const f32x4 r5 = Weights<R>::w[0] * uc;
       f32x4 dxx = r5, dyy = r5, dzz = r5;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
       float win[4 + 8 * ZF];
 #pragma unroll
       for (int j = 0; j < ZF; ++j) {
-        const f32x4 l = cur[row * ROWF4 + lane + j], h = cur[row * ROWF4 + ZF + lane + 1 + j];
+        const f32x4 l = cur[row * ROWF4 + col + j], h = cur[row * ROWF4 + ZF + col + 1 + j];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           win[4 * j + c] = l[c];
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
       for (int k = R; k >= 1; --k) {
         const float w = Weights<R>::w[k];
         dxx = dxx + w * (ring[r][R - k] + ring[r][R + k]);
-        dyy = dyy + w * (cur[(row - k) * ROWF4 + ZF + lane] + cur[(row + k) * ROWF4 + ZF + lane]);
+        dyy = dyy + w * (cur[(row - k) * ROWF4 + ZF + col] + cur[(row + k) * ROWF4 + ZF + col]);
         const f32x4 zm = f32x4{win[4 * ZF - k], win[4 * ZF + 1 - k], win[4 * ZF + 2 - k], win[4 * ZF + 3 - k]};
         const f32x4 zp = f32x4{win[4 * ZF + k], win[4 * ZF + 1 + k], win[4 * ZF + 2 + k], win[4 * ZF + 3 + k]};
         dzz = dzz + w * (zm + zp);
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
     }
     // plane p+1 into the other buffer, rings forward
 #pragma unroll
-    for (int r = 0; r < RW; ++r) nxt[(R + wave * RW + r) * ROWF4 + ZF + lane] = ring[r][R + 1];
+    for (int r = 0; r < RW; ++r) nxt[(R + (wave * RW + r) * RPS + sub) * ROWF4 + ZF + col] = ring[r][R + 1];
 #pragma unroll
     for (int q = 0; q < NPT; ++q) {
       if (pvalid[q]) nxt[pslot[q]] = aq[q][0];
@@ -310,12 +316,12 @@ int env_int_orders(const char *name, int fallback) {
 }
 
 // Workgroups of the marching sweep that one compute unit holds at a time (registers and LDS decide).
-template <int R, int RW, int D, bool NT, bool DAMPED>
+template <int R, int RW, int D, bool NT, bool DAMPED, int LPR>
 int march_workgroups_per_cu() {
   static int n = 0;
   if (n == 0) {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW, D, NT, DAMPED>, 512, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, stencil_order_march_kernel<R, RW, D, NT, DAMPED, LPR>, 512, 0) != hipSuccess ||
         v < 1)
       v = 1;
     n = v;
@@ -323,15 +329,15 @@ int march_workgroups_per_cu() {
   return n;
 }
 
-template <int R, int RW, int D, bool NT, bool DAMPED = false>
+template <int R, int RW, int D, bool NT, bool DAMPED = false, int LPR = 64>
 void launch_order_march(const StencilArgs &a, hipStream_t s, DampTerm dm = DampTerm{nullptr, 0.0F, 0.0F}) {
-  constexpr int TY = 8 * RW;
+  constexpr int TY = 8 * RW * (64 / LPR), TZ = 4 * LPR;
   const int ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
-  const int nyt = (ey + TY - 1) / TY, nzt = (ez + 255) / 256;
+  const int nyt = (ey + TY - 1) / TY, nzt = (ez + TZ - 1) / TZ;
   const long tiles = (long)nyt * nzt;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long slots = (long)cus * march_workgroups_per_cu<R, RW, D, NT, DAMPED>();
+  const long slots = (long)cus * march_workgroups_per_cu<R, RW, D, NT, DAMPED, LPR>();
   // x-chunks: the device works through ceil(workgroups / slots) rounds of (chunk length + lead-in), where
   // the lead-in — the 2R planes a chunk loads before its first result, without arithmetic — counts as R
   // planes.  Take the number of chunks that minimises the product.
@@ -350,7 +356,7 @@ void launch_order_march(const StencilArgs &a, hipStream_t s, DampTerm dm = DampT
   const int forced = env_int_orders("FDTD_ORDER_XCHUNK", 0);
   const int xchunk = forced > 0 ? forced : (int)((ex + nchunks - 1) / nchunks);
   nchunks = (ex + xchunk - 1) / xchunk;
-  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT, DAMPED>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s,
+  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT, DAMPED, LPR>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s,
                      a, xchunk, nyt, nzt, dm);
 }
 
@@ -415,11 +421,16 @@ static int sweep_order(const struct fdtd_geom *g, const float *m, const float *d
     // non-temporal stores: the level written is not read again before the next sweep has streamed the
     // whole field through the caches (FDTD_ORDER_NT = 0 keeps plain stores, for measurements)
     const int nt = env_int_orders("FDTD_ORDER_NT", 1);
-#define ORDER_MARCH(R_)                                                    \
-  case R_:                                                                 \
-    if (damp) launch_order_march<R_, 2, 1, true, true>(a, s, dm);          \
-    else if (nt) launch_order_march<R_, 2, 1, true>(a, s);                 \
-    else launch_order_march<R_, 2, 1, false>(a, s);                        \
+    // rows that fill multiples of 128 cells better than multiples of 256 (384 = 3 x 128): half a wave per row
+    const int lpr_auto = ((ez + 127) / 128) * 128 < ((ez + 255) / 256) * 256 ? 32 : 64;
+    const int lpr = env_int_orders("FDTD_ORDER_LPR", lpr_auto) == 32 ? 32 : 64;
+#define ORDER_MARCH(R_)                                                                    \
+  case R_:                                                                                 \
+    if (damp && lpr == 32) launch_order_march<R_, 2, 1, true, true, 32>(a, s, dm);         \
+    else if (damp) launch_order_march<R_, 2, 1, true, true>(a, s, dm);                     \
+    else if (lpr == 32) launch_order_march<R_, 2, 1, true, false, 32>(a, s);               \
+    else if (nt) launch_order_march<R_, 2, 1, true>(a, s);                                 \
+    else launch_order_march<R_, 2, 1, false>(a, s);                                        \
     break;
     switch (R) {
       ORDER_MARCH(2)

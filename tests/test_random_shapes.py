@@ -125,6 +125,8 @@ def test_space_orders_and_forward_operator_on_random_boxes(pkg, hiplib, monkeypa
     forward = bool(rng.integers(0, 2))
     monkeypatch.setenv("FDTD_ORDER_MARCH", "2" if march else "0")
     monkeypatch.setenv("FDTD_ORDER_XCHUNK", str(int(rng.integers(4, 30))))
+    if rng.integers(0, 2):
+        monkeypatch.setenv("FDTD_ORDER_LPR", "32")
     H = order
     n = (int(rng.integers(5, 40)), int(rng.integers(5, 44)), [int(rng.integers(5, 60)), int(rng.integers(200, 330))][int(rng.integers(0, 2))])
     shape = tuple(v + 2 * H for v in n)

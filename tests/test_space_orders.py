@@ -151,11 +151,13 @@ def _one_sweep(pkg, hiplib, order, n, bounds, seed, monkeypatch=None):
     ((36, 37, 131), (2, 33, 3, 30, 5, 127)),         # sub-range, z_m not a multiple of 4
     ((70, 16, 515), (0, 69, 0, 15, 1, 513)),         # three z-tiles, the last one a single cell wide; several x-chunks
 ])
-def test_marching_sweep_gives_the_oracle_bits(pkg, hiplib, monkeypatch, order, n, bounds):
+@pytest.mark.parametrize("lpr", ["64", "32"])
+def test_marching_sweep_gives_the_oracle_bits(pkg, hiplib, monkeypatch, order, n, bounds, lpr):
     """The marching sweep (x-ring in registers, current plane in LDS) on boxes that exercise its masks, forced on
     whatever the size of the box, with short x-chunks so that several chunks meet."""
     monkeypatch.setenv("FDTD_ORDER_MARCH", "2")
     monkeypatch.setenv("FDTD_ORDER_XCHUNK", "16")
+    monkeypatch.setenv("FDTD_ORDER_LPR", lpr)      # tiles of 16 rows x 256 cells / 32 rows x 128 cells
     u, u_ref = _one_sweep(pkg, hiplib, order, n, bounds, 900 + order)
     assert ob.bits_equal(u, u_ref), (order, n)
     # the cells outside the box are untouched
