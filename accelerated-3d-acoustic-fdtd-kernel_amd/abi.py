@@ -122,6 +122,8 @@ def lib():
     L.fdtd_hip_release_device_copies.restype = None
     L.fdtd_hip_last_call_phases.argtypes = [C.POINTER(C.c_double * 4)]
     L.fdtd_hip_last_call_phases.restype = None
+    L.fdtd_hip_last_call_uploads.argtypes = [C.POINTER(C.c_int * 4)]
+    L.fdtd_hip_last_call_uploads.restype = None
     L.fdtd_hip_stencil_step.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p]
     L.fdtd_hip_stencil_step.restype = C.c_int

@@ -5,6 +5,11 @@
 
 #include "../../include/fdtd_abi.h"
 
+// FDTD_HALO / FDTD_RADIUS in this library's sources mean the order-4 layout its order-4 kernels are written
+// for; the higher orders take their padding as an argument.
+static_assert(FDTD_STENCIL_ORDER == 4 && FDTD_HALO == 4 && FDTD_RADIUS == 2,
+              "build the library without -DFDTD_STENCIL_ORDER: the space order is a run-time choice here");
+
 // Everything a stencil sweep needs, passed by value in the kernarg segment (scalar
 // loads, no per-thread cost).  Level pointers already include the ring offset.
 struct StencilArgs {

@@ -838,6 +838,13 @@ bool fdtd_march2_preferred(const struct fdtd_geom *g) {
 // planes beyond the range on either side; inside the domain those planes are computed here as
 // well (from cur 4 planes and prev 2 planes beyond the range), bit for bit as their owner
 // computes them, and with the same source corners added.
+// flags bit 16 (internal, set by fdtd_hip_two_steps_slab_noalloc only): `scratch` is the per-device static
+// array.  A call that needs more of it than it holds is refused, and calls that use it are ordered one after
+// the other whatever their streams (static_scratch_begin / _end below).
+constexpr int M2_FLAG_STATIC_SCRATCH = 1 << 16;
+static int static_scratch_begin(hipStream_t s);
+static int static_scratch_end(hipStream_t s);
+
 int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *src,
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
@@ -930,12 +937,25 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // One sweep launch and nothing else: the two events take the start and stop times of that
   // dispatch itself (what a profiler reports as the kernel's duration); otherwise they are
   // recorded on the stream around everything the call launches.
-  const int per_launch = env_int2("FDTD_FUSE2_WGS", 256);
+  int per_launch = env_int2("FDTD_FUSE2_WGS", 256);   // workgroups per launch (stride of the launch loop below)
+  if (per_launch < 1) per_launch = 256;
   const bool dispatch_times = fuse && ev_begin && ev_end && nzt == 1 && !many &&
                               (long)ntile * ((ex + xchunk - 1) / xchunk) <= per_launch;
   if (ev_begin && !dispatch_times) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
 
   const long plane = (long)g->nyp * g->nzp;
+  const bool static_scratch_call = (flags & M2_FLAG_STATIC_SCRATCH) != 0;
+  if (!fuse && static_scratch_call) {
+    if (scratch_floats < (long)(ex + 4) * plane) {
+      fprintf(stderr,
+              "[fdtd-hip] fdtd_hip_two_steps_slab_noalloc: %d planes of %d x %d cells need %ld floats of work space, "
+              "the static buffer holds %ld; use fdtd_hip_two_steps_slab with a caller buffer\n",
+              ex, g->nyp, g->nzp, (long)(ex + 4) * plane, scratch_floats);
+      return (int)hipErrorInvalidValue;
+    }
+    const int rc = static_scratch_begin(s);
+    if (rc) return rc;
+  }
   if (!fuse && scratch && scratch_floats >= (long)(ex + 4) * plane) {
     // Thin range next to other ranges that are being updated at the same time (the boundary zone
     // of a slab): u(time+1) on the range grown by two planes is built in `scratch`, so nothing is
@@ -961,6 +981,10 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     FDTD_HIP_CHECK(hipMemcpyAsync(next1 + (long)(back_lo + FDTD_HALO) * plane,
                                   scratch + (long)(back_lo - (g->x_m - 2)) * plane,
                                   (size_t)(back_hi - back_lo + 1) * plane * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (static_scratch_call) {   // the array's last use in this call is the copy above
+      const int rc2 = static_scratch_end(s);
+      if (rc2) return rc2;
+    }
     if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
     if (has_src)
       rc = fdtd_inject_level(g, m, src, src_coords, next2, time + 1, p_src_m, p_src_M, src_stride, coord_stride,
@@ -1105,7 +1129,7 @@ extern "C" int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, 
                                      int src_stride, int coord_stride, int variant, int flags,
                                      void *ev_begin, void *ev_end, void *stream) {
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, flags, 0, 0, stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end,
+                             coord_stride, variant, flags & 0xffff, 0, 0, stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end,
                              nullptr, 0);
 }
 
@@ -1118,7 +1142,7 @@ extern "C" int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m
                                        int global_nx, float *scratch, long scratch_floats, void *stream) {
   if (global_nx <= 0) return (int)hipErrorInvalidValue;
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, flags, x_shift, global_nx, stream, nullptr, nullptr, scratch,
+                             coord_stride, variant, flags & 0xffff, x_shift, global_nx, stream, nullptr, nullptr, scratch,
                              scratch_floats);
 }
 
@@ -1130,31 +1154,69 @@ extern "C" int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m
 // process ends); the address is looked up once per device, with that device current, and from
 // then on only that pointer is used: in host code the array's name is not a device address.
 // The array keeps the previous call's contents; the path overwrites all (ex + 4) planes it reads
-// before it reads them, so nothing has to be cleared.  Calls that overlap in time on one GPU
-// share the array and race.
+// before it reads them, so nothing has to be cleared.  All calls on one GPU share the array.  Calls
+// that use it are ordered: each records an event behind its last use of the array, and a call on
+// another stream makes its stream wait for that event before it touches the array (calls on one
+// stream are ordered by the stream).  Ranges that take the fused sweep do not use the array at all
+// and are neither limited in size nor ordered.
 static __device__ __align__(256) float static_scratch[FDTD_STATIC_SCRATCH_FLOATS];
 
 namespace {
 constexpr int kMaxDevices = 64;
-float *g_static_scratch_ptr[kMaxDevices] = {};
+struct StaticScratch {
+  float *ptr = nullptr;            // device address of static_scratch on this device
+  hipEvent_t last_use = nullptr;   // recorded behind the last use of the array
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+};
+StaticScratch g_static_scratch[kMaxDevices];
 std::mutex g_static_scratch_mutex;
 
-// Device address of static_scratch on the current device (looked up at the first call there).
-int static_scratch_on_current_device(float **out) {
+// Set-up for the current device at the first call there: the array's device address and the event that
+// orders its users (created here so that later calls create nothing).
+int static_scratch_on_current_device(StaticScratch **out) {
   int dev = -1;
   FDTD_HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices) return (int)hipErrorInvalidDevice;
   std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
-  if (!g_static_scratch_ptr[dev]) {
+  StaticScratch &ss = g_static_scratch[dev];
+  if (!ss.ptr) {
     float *p = nullptr;
     FDTD_HIP_CHECK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(static_scratch)));
     if (!p) return (int)hipErrorInvalidSymbol;
-    g_static_scratch_ptr[dev] = p;
+    FDTD_HIP_CHECK(hipEventCreateWithFlags(&ss.last_use, hipEventDisableTiming));
+    ss.ptr = p;
   }
-  *out = g_static_scratch_ptr[dev];
+  *out = &ss;
   return 0;
 }
 }  // namespace
+
+static int static_scratch_begin(hipStream_t s) {
+  StaticScratch *ss = nullptr;
+  const int rc = static_scratch_on_current_device(&ss);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+  if (ss->used && ss->last_stream != s) {
+    const hipError_t e = hipStreamWaitEvent(s, ss->last_use, 0);
+    if (e != hipSuccess) {
+      fprintf(stderr, "[fdtd-hip] fdtd_hip_two_steps_slab_noalloc: cannot order this call behind the previous user of "
+                      "the static work space on this GPU (%s)\n", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  return 0;
+}
+static int static_scratch_end(hipStream_t s) {
+  StaticScratch *ss = nullptr;
+  const int rc = static_scratch_on_current_device(&ss);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+  FDTD_HIP_CHECK(hipEventRecord(ss->last_use, s));
+  ss->last_stream = s;
+  ss->used = true;
+  return 0;
+}
 
 extern "C" int fdtd_hip_two_steps_slab_noalloc(const struct fdtd_geom *g, const float *m, const float *src,
                                                const float *src_coords, const float *cur, const float *prev,
@@ -1162,20 +1224,13 @@ extern "C" int fdtd_hip_two_steps_slab_noalloc(const struct fdtd_geom *g, const 
                                                int src_stride, int coord_stride, int variant, int flags,
                                                int x_shift, int global_nx, void *stream) {
   if (!g || global_nx <= 0) return (int)hipErrorInvalidValue;
-  const long need = (long)(g->x_M - g->x_m + 5) * g->nyp * g->nzp;
-  if (g->x_M >= g->x_m && need > (long)FDTD_STATIC_SCRATCH_FLOATS) {
-    fprintf(stderr,
-            "[fdtd-hip] fdtd_hip_two_steps_slab_noalloc: %d planes of %d x %d cells need %ld floats of work space, "
-            "the static buffer holds %ld; use fdtd_hip_two_steps_slab with a caller buffer\n",
-            g->x_M - g->x_m + 1, g->nyp, g->nzp, need, (long)FDTD_STATIC_SCRATCH_FLOATS);
-    return (int)hipErrorInvalidValue;
-  }
-  float *ws = nullptr;
-  const int rc = static_scratch_on_current_device(&ws);
+  StaticScratch *ss = nullptr;
+  const int rc = static_scratch_on_current_device(&ss);
   if (rc) return rc;
+  // the size of the range is checked where the path is chosen: only the two-sweep path needs the array
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, flags, x_shift, global_nx, stream, nullptr, nullptr, ws,
-                             (long)FDTD_STATIC_SCRATCH_FLOATS);
+                             coord_stride, variant, (flags & 0xffff) | M2_FLAG_STATIC_SCRATCH, x_shift, global_nx, stream,
+                             nullptr, nullptr, ss->ptr, (long)FDTD_STATIC_SCRATCH_FLOATS);
 }
 
 extern "C" int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const float *src,

@@ -120,6 +120,16 @@ struct SpareLevel {
 };
 SpareLevel g_spare[kMaxSpareDevices];
 std::mutex g_spare_mutex;
+
+// Frees the fourth level buffer kept on `dev` (the current device) unless a time loop is using it.
+void release_spare_level(int dev) {
+  if (dev < 0 || dev >= kMaxSpareDevices) return;
+  std::lock_guard<std::mutex> lock(g_spare_mutex);
+  SpareLevel &sp = g_spare[dev];
+  if (!sp.level || sp.in_use) return;
+  (void)hipFree(sp.level);
+  sp = SpareLevel();
+}
 }  // namespace
 
 static int time_loop_fused(const struct fdtd_geom *g, const float *m, const float *src,
@@ -472,24 +482,62 @@ struct DeviceBuffers {
   }
 };
 
-// Device copies that outlive an operator call.  The reference's OpenACC operator deletes its
-// device copies only `if(devicerm)` (openacc.cpp:208-212); with devicerm = 0 they stay on the
-// device and the next call's `enter data copyin` finds them present and transfers nothing.  Here a
-// call with devicerm = 0 leaves its device arrays in this table, keyed by device and by the
-// caller's host pointers and shapes; a later call with the same key works on them without
-// uploading u or m again (u is still copied back to the caller at the end of every call, as
-// `exit data copyout` does; src and coords are small and always refreshed).  Set
-// FDTD_RESIDENT_REUPLOAD_U=1 if the host modifies u between calls.  devicerm != 0 frees the
-// entry at the end of the call; fdtd_hip_release_device_copies() frees all of them.
+// Device copies that outlive an operator call.  The reference's OpenACC operator copies u out and
+// releases it at the end of every call (`exit data copyout(u)`, openacc.cpp:208) and deletes m, src
+// and src_coords only `if(devicerm)` (openacc.cpp:209-212): with devicerm = 0 those three stay on the
+// device, and the next call's `enter data copyin` finds them present and transfers nothing, while u is
+// uploaded again.  The reference's CUDA operators ignore devicerm and upload everything on every call
+// (cuda.cu:204-214,321).  Here:
+//   * Kernel_OpenACC with devicerm = 0 leaves its device arrays in this table, keyed by device, the
+//     caller's m pointer, the padded shape and a content tag of m (below).  A later call with the same
+//     key uploads u, src and src_coords (src and coords are a few KB; refreshing them is never wrong) and
+//     computes on the resident m.
+//   * The other operators do the same only when FDTD_RESIDENT_ALL_OPERATORS=1; by default they upload
+//     and free everything, whatever devicerm says, like the reference's.
+//   * FDTD_RESIDENT_KEEP_U=1 keeps u resident as well (no upload when the caller passes the same u
+//     pointer again): for callers that advance one field through successive calls and never edit it on
+//     the host in between.  It is not what the reference does.
+// An OpenACC runtime keys its present table by host address alone, so a host array that was freed and
+// allocated again at the same address, or edited in place, silently computes on stale device data.  The
+// content tag closes most of that gap without reading all of m: a hash of its first and last 4 KB and of
+// 4096 words spread evenly over it.  A tag that differs makes the call upload m again.
+// devicerm != 0 frees the entry at the end of the call; fdtd_hip_release_device_copies() frees all of them.
 struct Resident {
   int device = 0;
   const void *u_host = nullptr, *m_host = nullptr;
   int nxp = 0, nyp = 0, nzp = 0;
+  unsigned long long m_tag = 0;
+  bool u_valid = false;     // d.u holds the state the last call left (FDTD_RESIDENT_KEEP_U)
   DeviceBuffers d;
 };
 std::vector<Resident> g_resident;
-std::mutex g_resident_mutex;
+std::mutex g_resident_mutex;   // guards g_resident only; never held across a time loop
 double g_last_phases[4] = {0, 0, 0, 0};   // allocate, to device, time loop, to host (ms) of the last operator call
+int g_last_uploads[4] = {0, 0, 0, 0};     // did the last operator call upload u, m, src, coords?
+
+unsigned long long content_tag(const float *p, size_t n) {
+  unsigned long long h = 1469598103934665603ULL;   // FNV-1a over the sampled words
+  auto mix = [&h](unsigned v) {
+    for (int b = 0; b < 4; ++b) {
+      h ^= (v >> (8 * b)) & 0xffu;
+      h *= 1099511628211ULL;
+    }
+  };
+  const unsigned *w = (const unsigned *)p;
+  const size_t edge = n < 1024 ? n : 1024;
+  for (size_t i = 0; i < edge; ++i) mix(w[i]);
+  for (size_t i = n - edge; i < n; ++i) mix(w[i]);
+  const size_t stride = n / 4096 ? n / 4096 : 1;
+  for (size_t i = 0; i < n; i += stride) mix(w[i]);
+  mix((unsigned)n);
+  mix((unsigned)(n >> 32));
+  return h;
+}
+
+bool env_flag(const char *name) {
+  const char *e = getenv(name);
+  return e && atoi(e) != 0;
+}
 
 // Shape checks shared by the operators.  The reference trusts its caller; a wrong shape
 // there is an out-of-bounds access, here it is hipErrorInvalidValue
@@ -553,57 +601,69 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
   double t_alloc = 0, t_h2d = 0, t_loop = 0, t_d2h = 0;
   int cur_dev = 0;
   FDTD_HIP_CHECK(hipGetDevice(&cur_dev));
-  std::lock_guard<std::mutex> lock(g_resident_mutex);   // operator calls are sequential (main.cpp:394)
-  // a resident entry of an earlier devicerm = 0 call with the same host arrays and shapes?
-  int slot = -1;
-  for (size_t i = 0; i < g_resident.size(); ++i) {
-    Resident &r = g_resident[i];
-    if (r.device != cur_dev || r.u_host != u_vec->data) continue;
-    if (r.m_host == m_vec->data && r.nxp == g.nxp && r.nyp == g.nyp && r.nzp == g.nzp) {
-      slot = (int)i;
-    } else {   // same host array, other shape: the old copies are stale
-      r.d.release();
+  // Which operators honour devicerm = 0 (see Resident above)
+  const bool may_stay = variant == FDTD_VARIANT_FLAT || env_flag("FDTD_RESIDENT_ALL_OPERATORS");
+  const bool keep_u = env_flag("FDTD_RESIDENT_KEEP_U") && !env_flag("FDTD_RESIDENT_REUPLOAD_U");
+  // A resident entry of an earlier devicerm = 0 call with the same m array and shapes?  It is taken out of
+  // the table for the duration of the call (a concurrent call with the same arrays misses and makes its own
+  // copies) and put back at the end if devicerm = 0.
+  Resident res;
+  bool reuse = false;
+  if (may_stay) {
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    for (size_t i = 0; i < g_resident.size(); ++i) {
+      Resident &r = g_resident[i];
+      if (r.device != cur_dev || r.m_host != m_vec->data) continue;
+      if (r.nxp == g.nxp && r.nyp == g.nyp && r.nzp == g.nzp) {
+        res = r;
+        reuse = true;
+      } else {   // same host array, other shape: the old copies are stale
+        r.d.release();
+      }
       g_resident.erase(g_resident.begin() + (long)i);
+      break;
     }
-    break;
   }
-  const bool reuse = slot >= 0;
-  Resident local;
-  Resident &res = reuse ? g_resident[(size_t)slot] : local;
   DeviceBuffers &d = res.d;
-  struct Cleanup {   // error paths: nothing of this call stays on the device
-    Resident *r; int slot; bool armed = true;
+  struct Cleanup {   // unless the entry goes back into the table, nothing of this call stays on the device
+    Resident *r; bool armed = true;
     ~Cleanup() {
-      if (!armed) return;
-      r->d.release();
-      if (slot >= 0) g_resident.erase(g_resident.begin() + slot);
+      if (armed) r->d.release();
     }
-  } cleanup{&res, slot};
+  } cleanup{&res};
   StagedCopier &copier = staged_copier_for_current_device();
   if (!reuse) {
     FDTD_HIP_CHECK(hipMalloc((void **)&d.u, 3 * vol * sizeof(float)));
     FDTD_HIP_CHECK(hipMalloc((void **)&d.m, vol * sizeof(float)));
   }
   t_alloc = now();
-  const bool reupload_u = getenv("FDTD_RESIDENT_REUPLOAD_U") && atoi(getenv("FDTD_RESIDENT_REUPLOAD_U")) != 0;
-  if (!reuse || reupload_u) {
+  const bool tagging = may_stay && (reuse || !devicerm);
+  const unsigned long long tag = tagging ? content_tag((const float *)m_vec->data, vol) : 0;
+  const bool u_present = reuse && keep_u && res.u_valid && res.u_host == u_vec->data;
+  const bool m_present = reuse && res.m_tag == tag;
+  res.u_valid = false;
+  if (!u_present) {
     rc = copier.to_device(d.u, u_vec->data, 3 * vol * sizeof(float));
     if (rc) return rc;
   }
-  if (!reuse) {
+  if (!m_present) {
     rc = copier.to_device(d.m, m_vec->data, vol * sizeof(float));
     if (rc) return rc;
   }
+  g_last_uploads[0] = !u_present; g_last_uploads[1] = !m_present;
+  g_last_uploads[2] = g_last_uploads[3] = src_nonempty;
   if (src_nonempty) {
     if (d.n_src < n_src) {
       if (d.src) FDTD_HIP_CHECK(hipFree(d.src));
       d.src = nullptr;
+      d.n_src = 0;
       FDTD_HIP_CHECK(hipMalloc((void **)&d.src, n_src * sizeof(float)));
       d.n_src = n_src;
     }
     if (d.n_coords < n_coords) {
       if (d.coords) FDTD_HIP_CHECK(hipFree(d.coords));
       d.coords = nullptr;
+      d.n_coords = 0;
       FDTD_HIP_CHECK(hipMalloc((void **)&d.coords, n_coords * sizeof(float)));
       d.n_coords = n_coords;
     }
@@ -637,13 +697,22 @@ int run_operator(int variant, dataobj *m_vec, dataobj *src_vec, dataobj *coords_
             g.nxp, g.nyp, g.nzp, reuse ? " (device copies of an earlier call)" : "", t_alloc - t_begin,
             t_h2d - t_alloc, t_loop - t_h2d, t_d2h - t_loop);
   if (rc) return rc;
-  if (devicerm) return 0;          // cleanup frees the arrays and drops the entry (openacc.cpp:209-212)
+  // devicerm != 0 (or an operator that ignores it): the cleanup frees the arrays, and the fourth level buffer
+  // the two-step time loop keeps per device goes as well — like the reference, the call leaves nothing behind
+  // (cuda.cu:320, openacc.cpp:209-212).
+  if (devicerm || !may_stay) {
+    release_spare_level(cur_dev);
+    return 0;
+  }
   cleanup.armed = false;           // devicerm = 0: the device copies stay
-  if (!reuse) {
-    local.device = cur_dev;
-    local.u_host = u_vec->data; local.m_host = m_vec->data;
-    local.nxp = g.nxp; local.nyp = g.nyp; local.nzp = g.nzp;
-    g_resident.push_back(local);
+  res.device = cur_dev;
+  res.u_host = u_vec->data; res.m_host = m_vec->data;
+  res.nxp = g.nxp; res.nyp = g.nyp; res.nzp = g.nzp;
+  res.m_tag = tag;
+  res.u_valid = keep_u;
+  {
+    std::lock_guard<std::mutex> lock(g_resident_mutex);
+    g_resident.push_back(res);
   }
   return 0;
 }
@@ -690,6 +759,11 @@ extern "C" void fdtd_hip_release_device_copies(void) {
 // time loop, copy to the host.
 extern "C" void fdtd_hip_last_call_phases(double out_ms[4]) {
   for (int i = 0; i < 4; ++i) out_ms[i] = g_last_phases[i];
+}
+
+// Which host arrays the last operator call copied to the device: u, m, src, src_coords (1 or 0 each).
+extern "C" void fdtd_hip_last_call_uploads(int out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = g_last_uploads[i];
 }
 
 static int optimized_variant() {

@@ -370,6 +370,10 @@ bool order_march_takes(const StencilArgs &a, int H) {
       a.z_M > a.nzp - 2 * H - 1)
     return false;
   if ((long)a.nyp * a.nzp >= (1L << 30)) return false;   // offsets inside a plane are ints
+  // A lane's 16-byte access starts at most R cells behind z_M and must end inside the row (H cells of padding):
+  // R + 3 <= H holds from order 6 on; at order 4 a row that reaches the end of the interior with a z extent
+  // of 4k + 3 cells would touch the first float of the next row, so such boxes stay on the other kernel.
+  if (H == 4 && a.z_M == a.nzp - 2 * H - 1 && (a.z_M - a.z_m + 1) % 4 == 3) return false;
   if (mode == 2) return true;
   const long ex = a.x_M - a.x_m + 1, ey = a.y_M - a.y_m + 1, ez = a.z_M - a.z_m + 1;
   // measured on MI355X: from 256^3 cells on the marching sweep is the faster one at every order; below, the

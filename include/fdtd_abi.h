@@ -30,11 +30,15 @@
 extern "C" {
 #endif
 
-/* Space order 4: radius-2 star stencil, padding of 4 cells per side
- * (main.cpp:27-32, cuda.cu:55). */
+/* Space order of the caller's arrays: 4 (radius-2 star stencil, padding of 4 cells per side) unless the
+ * including program is compiled with -DFDTD_STENCIL_ORDER=6, 8, 10 or 12, the way the reference driver takes
+ * -DSTENCIL_ORDER with HALO = STENCIL_ORDER (main.cpp:27-32; cuda.cu:55).  The macros describe the CALLER's
+ * arrays; the library itself takes the order per call or per process (fdtd_hip_set_space_order). */
+#ifndef FDTD_STENCIL_ORDER
 #define FDTD_STENCIL_ORDER 4
-#define FDTD_RADIUS 2
-#define FDTD_HALO 4
+#endif
+#define FDTD_RADIUS (FDTD_STENCIL_ORDER / 2)
+#define FDTD_HALO FDTD_STENCIL_ORDER
 /* The first FDTD_WARMUP_STEPS time steps of a call are real steps that are not
  * timed (openacc.cpp:5,90-93; cuda.cu:56,232). */
 #define FDTD_WARMUP_STEPS 5
@@ -110,14 +114,22 @@ int Kernel_HIP_MultiGPU(FDTD_OPERATOR_ARGS);
 /* Number of slabs the last Kernel_HIP_MultiGPU call was cut into (1: handed to one device). */
 int fdtd_hip_multigpu_last_slab_count(void);
 
-/* Device copies across calls.  An operator call with devicerm = 0 leaves its device arrays on the
- * device, as openacc.cpp:208-212 does (delete ... if(devicerm)); a later call with the same host
- * arrays (same u and m pointers, same shapes, same device) computes on them without uploading u or
- * m again (src and src_coords are small and always refreshed); u is copied back to the host at
- * the end of every call either way.  If the host changes u between two such calls, set
- * FDTD_RESIDENT_REUPLOAD_U=1.  devicerm != 0 frees the copies at the end of the call;
- * fdtd_hip_release_device_copies frees whatever earlier calls left behind. */
+/* Device copies across calls.  openacc.cpp:208-212 copies u out and releases it at the end of every call and
+ * deletes m, src and src_coords only `if(devicerm)`; the reference's CUDA operators ignore devicerm and upload
+ * everything on every call (cuda.cu:204-214,321).  The same here: Kernel_OpenACC with devicerm = 0 leaves m (and
+ * the device allocations) behind, and a later call with the same m pointer, padded shape and device computes on
+ * that copy; u, src and src_coords are uploaded on every call, u is copied back at the end of every call.  The
+ * other operators behave like that only with FDTD_RESIDENT_ALL_OPERATORS=1 in the environment; by default they
+ * upload and free everything whatever devicerm says.  An OpenACC runtime would compute on stale data if the host
+ * array was freed and allocated again at the same address or edited in place; here the entry also carries a
+ * content tag of m (hash of its first and last 4 KB and of 4096 words spread over it), and a tag that differs
+ * makes the call upload m again.  FDTD_RESIDENT_KEEP_U=1 (not reference behaviour) keeps u on the device too:
+ * a later call with the same u pointer continues from the device copy without reading the host's u.
+ * devicerm != 0 frees the copies at the end of the call; fdtd_hip_release_device_copies frees whatever earlier
+ * calls left behind.  Kernel_HIP_Forward and Kernel_HIP_MultiGPU always upload and free everything. */
 void fdtd_hip_release_device_copies(void);
+/* Which host arrays the last operator call copied to the device: out = {u, m, src, src_coords}, 1 or 0 each. */
+void fdtd_hip_last_call_uploads(int out[4]);
 /* Host-side phase times of the last operator call, in milliseconds: allocation, copies to the
  * device, time loop, copy to the host. */
 void fdtd_hip_last_call_phases(double out_ms[4]);

@@ -83,6 +83,26 @@ def test_forward_operator_through_the_marching_sweep(pkg, hiplib, monkeypatch, n
     assert ob.bits_equal(u, u_ref) and ob.bits_equal(rec, rec_ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [(64, 512, 512), (96, 448, 384)])
+def test_forward_operator_full_size_default_path(pkg, hiplib, n):
+    """What ships by default, with no switch set: a box of 16 M cells, which the size rule sends to the large-box
+    sweep of the damped update, a dozen steps with a sponge, sources and receivers against the restatement."""
+    import os
+    for name in ("FDTD_ORDER_MARCH", "FDTD_ORDER_XCHUNK", "FDTD_ORDER_LPR", "FDTD_ORDER_MARCH_MIN_CELLS",
+                 "FDTD_FUSE2_MIN_CELLS", "FDTD_FUSE2"):
+        assert name not in os.environ
+    nt = 12
+    u, m, src, coords, rec, rcoords, h = random_case(n, nt, 3, 5, 41)
+    damp = sponge(m.shape, 12, 40.0)
+    u_ref, rec_ref = u.copy(), rec.copy()
+    rc, _ = pkg.run_forward(ob.oracle().Oracle_Kernel_Forward, damp, m, rec_ref, rcoords, src, coords, u_ref, h=h)
+    assert rc == 0
+    rc, prof = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h)
+    assert rc == 0 and prof.section0 > 0
+    assert ob.bits_equal(u, u_ref) and ob.bits_equal(rec, rec_ref)
+
+
 def test_generic_restatement_at_order_4_is_the_order_4_restatement(pkg):
     """CPU: Oracle_Kernel_ForwardOrder(order = 4) gives the bits of Oracle_Kernel_Forward."""
     n, nt = (14, 12, 20), 9

@@ -61,42 +61,110 @@ def test_multigpu_operator_large_cross_section(pkg, hiplib, zone_fused, monkeypa
     assert prof.section0 > 0
 
 
-def test_device_copies_persist_with_devicerm_0(pkg, hiplib):
-    """openacc.cpp:208-212 deletes the device copies only `if(devicerm)`.  Two half-length calls, the first
-    with devicerm = 0, equal one full call bit for bit, and the second call uploads neither u nor m."""
+def _uploads(hiplib):
+    up = (C.c_int * 4)()
+    hiplib.fdtd_hip_last_call_uploads(C.byref(up))
+    return list(up)
+
+
+def test_device_copies_persist_with_devicerm_0(pkg, hiplib, monkeypatch):
+    """openacc.cpp:208-212: u is copied out and released at the end of every call, m / src / src_coords are
+    deleted only `if(devicerm)`.  Default mode: after a devicerm = 0 call of Kernel_OpenACC the next call uploads
+    u (the host's u is the state) but not m; the CUDA-named operators ignore devicerm like cuda.cu:321.  Opt-in
+    modes: FDTD_RESIDENT_ALL_OPERATORS extends this to every operator, FDTD_RESIDENT_KEEP_U keeps u as well."""
     n, nt = (64, 64, 512), 40
     u_full, m, src, coords = pkg.standard_inputs(*n, nt, 2)
     rng = np.random.default_rng(9)
     m[:] = rng.uniform(1, 3, size=m.shape).astype(np.float32)
-    u_half = u_full.copy()
+    u0 = u_full.copy()
     rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u_full)
     assert rc == 0
-    ph = (C.c_double * 4)()
-    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u_half, time_m=0, time_M=nt // 2 - 1, devicerm=0)
-    assert rc == 0
-    hiplib.fdtd_hip_last_call_phases(C.byref(ph))
-    first_h2d = ph[1]
-    mid = u_half.copy()
-    u_half[:] = np.nan        # the host copy is not read again: the device copy is the state
-    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u_half, time_m=nt // 2, time_M=nt - 1, devicerm=1)
-    assert rc == 0
-    hiplib.fdtd_hip_last_call_phases(C.byref(ph))
-    assert ob.bits_equal(u_half, u_full)
-    assert not ob.bits_equal(mid, u_full)
-    assert ph[1] < 0.25 * first_h2d, (ph[1], first_h2d)      # only src and coords went up
-    # devicerm = 1 dropped the copies: the next call starts from the host arrays again
-    u_again = np.zeros_like(u_full)
-    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u_again)
-    assert rc == 0 and ob.bits_equal(u_again, u_full)
-    # FDTD_RESIDENT_REUPLOAD_U=1: the host's u wins over the device copy
-    os.environ["FDTD_RESIDENT_REUPLOAD_U"] = "1"
+    half = dict(time_m=0, time_M=nt // 2 - 1)
+    rest = dict(time_m=nt // 2, time_M=nt - 1)
     try:
-        u2 = np.zeros_like(u_full)
-        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u2, time_m=0, time_M=nt // 2 - 1, devicerm=0)
+        # --- default: the reference's semantics, operator by operator ---
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=0, **half)
+        assert rc == 0 and _uploads(hiplib) == [1, 1, 1, 1]
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=1, **rest)
+        assert rc == 0 and _uploads(hiplib) == [1, 0, 1, 1]     # u from the host again, m was present
+        assert ob.bits_equal(u, u_full)
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u0.copy(), devicerm=1, **half)
+        assert rc == 0 and _uploads(hiplib) == [1, 1, 1, 1]     # devicerm = 1 dropped the copies
+        # a host edit of u between two calls is seen (the reference re-uploads u)
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=0, **half)
         assert rc == 0
-        u2[:] = 0.0
-        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u2, time_m=0, time_M=nt - 1, devicerm=1)
-        assert rc == 0 and ob.bits_equal(u2, u_full)
+        u[:] = u0
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=1, time_m=0, time_M=nt - 1)
+        assert rc == 0 and ob.bits_equal(u, u_full)
+        # the CUDA-named operators ignore devicerm (cuda.cu:321): everything goes up on every call
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, devicerm=0, **half)
+        assert rc == 0
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, devicerm=0, **rest)
+        assert rc == 0 and _uploads(hiplib) == [1, 1, 1, 1] and ob.bits_equal(u, u_full)
+
+        # --- every operator, u kept too: two half-length calls equal one full call, nothing but the sources goes up ---
+        monkeypatch.setenv("FDTD_RESIDENT_ALL_OPERATORS", "1")
+        monkeypatch.setenv("FDTD_RESIDENT_KEEP_U", "1")
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, devicerm=0, **half)
+        assert rc == 0
+        mid = u.copy()
+        u[:] = np.nan        # the host copy is not read again: the device copy is the state
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, devicerm=1, **rest)
+        assert rc == 0 and _uploads(hiplib) == [0, 0, 1, 1]
+        assert ob.bits_equal(u, u_full) and not ob.bits_equal(mid, u_full)
+        # devicerm = 1 dropped the copies: the next call starts from the host arrays again
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u)
+        assert rc == 0 and _uploads(hiplib) == [1, 1, 1, 1] and ob.bits_equal(u, u_full)
+        # another u array with the same m: u goes up, m stays
+        monkeypatch.delenv("FDTD_RESIDENT_KEEP_U")
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, devicerm=0, **half)
+        assert rc == 0
+        rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, devicerm=0, **rest)
+        assert rc == 0 and _uploads(hiplib) == [1, 0, 1, 1] and ob.bits_equal(u, u_full)
     finally:
-        del os.environ["FDTD_RESIDENT_REUPLOAD_U"]
+        hiplib.fdtd_hip_release_device_copies()
+
+
+def test_resident_m_is_revalidated(pkg, hiplib):
+    """A host array freed and allocated again at the same address with other values (or edited in place) must
+    not compute on the stale device copy: the entry's content tag of m differs and m is uploaded again."""
+    n, nt = (24, 20, 64), 12
+    u0, m, src, coords = pkg.standard_inputs(*n, nt, 2)
+    rng = np.random.default_rng(21)
+    try:
+        m[:] = rng.uniform(1, 3, size=m.shape).astype(np.float32)
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=0)
+        assert rc == 0
+        addr = m.ctypes.data
+        # "free and reallocate": same address, same shape, other values
+        m[:] = rng.uniform(1, 3, size=m.shape).astype(np.float32)
+        assert m.ctypes.data == addr
+        u = u0.copy()
+        u_ref = u0.copy()
+        ob.run_oracle(m, src, coords, u_ref)
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=0)
+        assert rc == 0 and _uploads(hiplib)[1] == 1
+        assert ob.bits_equal(u, u_ref)
+        # unchanged m: present, not uploaded, same bits
+        u = u0.copy()
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m, src, coords, u, devicerm=0)
+        assert rc == 0 and _uploads(hiplib)[1] == 0 and ob.bits_equal(u, u_ref)
+        # same address, another shape (a view of the same buffer): the old entry is dropped
+        n2 = (20, 24, 64)
+        u2, m2, src2, coords2 = pkg.standard_inputs(*n2, nt, 2)
+        m_view = m.reshape(-1)[:m2.size].reshape(m2.shape)
+        m_view[:] = rng.uniform(1, 3, size=m2.shape).astype(np.float32)
+        assert m_view.ctypes.data == addr
+        u2_ref = u2.copy()
+        ob.run_oracle(m_view, src2, coords2, u2_ref)
+        rc, _ = pkg.run_operator(hiplib.Kernel_OpenACC, m_view, src2, coords2, u2, devicerm=0)
+        assert rc == 0 and _uploads(hiplib)[1] == 1 and ob.bits_equal(u2, u2_ref)
+    finally:
         hiplib.fdtd_hip_release_device_copies()

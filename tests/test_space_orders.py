@@ -186,6 +186,27 @@ def test_operator_at_space_order_on_a_box_the_marching_sweep_takes(pkg, hiplib, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order,n", [(8, (64, 512, 512)), (12, (64, 512, 512)), (6, (96, 448, 384))])
+def test_operator_at_space_order_full_size_default_path(pkg, hiplib, order, n):
+    """What ships by default, with no switch set: boxes of 16 M cells and more, so the size rule sends them to the
+    marching sweep with the x-chunks its model chooses; 384-cell rows make the automatic choice take half-wave
+    rows.  A dozen steps with sources (one in the outermost cell) against the generic oracle."""
+    for name in ("FDTD_ORDER_MARCH", "FDTD_ORDER_XCHUNK", "FDTD_ORDER_LPR", "FDTD_ORDER_MARCH_MIN_CELLS"):
+        assert name not in __import__("os").environ
+    assert hiplib.fdtd_hip_set_space_order(order) == 0
+    try:
+        u0, m, src, coords, kw = padded_case(order, n, 12, 3, 170 + order, None, True)
+        u_ref = u0.copy()
+        ob.run_oracle_order(order, m, src, coords, u_ref, **kw)
+        u = u0
+        rc, prof = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u, **kw)
+        assert rc == 0 and prof.section0 > 0
+        assert ob.bits_equal(u, u_ref)
+    finally:
+        assert hiplib.fdtd_hip_set_space_order(4) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["noncubic_aniso", "ricker27_n32", "subrange_unaligned", "time_offset", "ricker30_n24_overlap"])
 def test_generic_kernel_at_order_4_gives_the_fixtures(pkg, hiplib, name):
     """The generic sweep and the scatter with an explicit padding, stepped by hand at order 4."""
