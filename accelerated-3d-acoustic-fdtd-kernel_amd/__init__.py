@@ -12,6 +12,7 @@ from .abi import (  # noqa: F401
     WARMUP_STEPS,
     Dataobj,
     Geom,
+    MultiGpuSession,
     Parity,
     Profiler,
     VARIANTS,

@@ -11,6 +11,7 @@ import numpy as np
 HALO = 4            # main.cpp:32, cuda.cu:55
 WARMUP_STEPS = 5    # openacc.cpp:5
 STATIC_SCRATCH_FLOATS = 4 << 20   # FDTD_STATIC_SCRATCH_FLOATS of fdtd_abi.h
+MULTIGPU_ONE_THREAD, MULTIGPU_NO_OVERLAP, MULTIGPU_NO_EXCHANGE = 1, 2, 4   # flags of fdtd_hip_multigpu_create
 VARIANTS = {"flat": 0, "naive": 1, "march": 2, "tile3d": 3, "vec": 4, "march2": 5, "rows": 6, "auto": -1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -118,6 +119,19 @@ def lib():
     L.fdtd_hip_source_inject_order.restype = C.c_int
     L.fdtd_hip_multigpu_last_slab_count.argtypes = []
     L.fdtd_hip_multigpu_last_slab_count.restype = C.c_int
+    L.fdtd_hip_multigpu_create.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.fdtd_hip_multigpu_destroy.argtypes = [C.c_void_p]
+    L.fdtd_hip_multigpu_set_sources.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_int, C.c_int]
+    L.fdtd_hip_multigpu_fill_standard_inputs.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.fdtd_hip_multigpu_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.fdtd_hip_multigpu_advance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Profiler)]
+    L.fdtd_hip_multigpu_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.fdtd_hip_multigpu_max_abs.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]
+    L.fdtd_hip_multigpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double * 10), C.c_int]
+    for name in ("create", "destroy", "set_sources", "fill_standard_inputs", "upload", "advance", "gather", "max_abs",
+                 "stats"):
+        getattr(L, "fdtd_hip_multigpu_" + name).restype = C.c_int
     L.fdtd_hip_release_device_copies.argtypes = []
     L.fdtd_hip_release_device_copies.restype = None
     L.fdtd_hip_last_call_phases.argtypes = [C.POINTER(C.c_double * 4)]
@@ -318,3 +332,70 @@ def compare_fields(test, ref):
     p = Parity()
     lib().fdtd_compare_fields(test.ctypes.data, ref.ctypes.data, test.size, C.byref(p))
     return p
+
+
+class MultiGpuSession:
+    """fdtd_hip_multigpu_* of fdtd_abi.h: the slabs of one domain on several devices (or several slabs on one),
+    owned by the library between calls."""
+
+    def __init__(self, geom, devices, flags=0):
+        self.L = lib()
+        self.geom = geom
+        self.devices = list(devices)
+        self.h = C.c_void_p()
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        rc = self.L.fdtd_hip_multigpu_create(C.byref(geom), len(self.devices), arr, flags, C.byref(self.h))
+        if rc:
+            raise RuntimeError(f"fdtd_hip_multigpu_create returned {rc}")
+
+    def _check(self, rc, what):
+        if rc:
+            raise RuntimeError(f"fdtd_hip_multigpu_{what} returned {rc}")
+
+    def set_sources(self, src, coords, p_src=None):
+        if src is None:
+            return self._check(self.L.fdtd_hip_multigpu_set_sources(self.h, None, 0, 1, None, 0, 3, 0, -1), "set_sources")
+        p_src = p_src or (0, src.shape[1] - 1)
+        self._check(self.L.fdtd_hip_multigpu_set_sources(self.h, src.ctypes.data, src.shape[0], src.shape[1],
+                                                         coords.ctypes.data, coords.shape[0], coords.shape[1],
+                                                         p_src[0], p_src[1]), "set_sources")
+
+    def fill_standard_inputs(self, nt, nsrc=1):
+        self._check(self.L.fdtd_hip_multigpu_fill_standard_inputs(self.h, nt, nsrc), "fill_standard_inputs")
+
+    def upload(self, u, m, time_m=0):
+        self._check(self.L.fdtd_hip_multigpu_upload(self.h, u.ctypes.data, None if m is None else m.ctypes.data, time_m),
+                    "upload")
+
+    def advance(self, time_m, time_M):
+        prof = Profiler(0.0, 0.0)
+        self._check(self.L.fdtd_hip_multigpu_advance(self.h, time_m, time_M, C.byref(prof)), "advance")
+        return prof.section0
+
+    def gather(self, u):
+        """All three ring slots into u[3][nxp][nyp][nzp]."""
+        for slot in range(3):
+            self._check(self.L.fdtd_hip_multigpu_gather(self.h, slot, u[slot].ctypes.data), "gather")
+
+    def max_abs(self):
+        mx, bad = C.c_float(0.0), C.c_long(0)
+        self._check(self.L.fdtd_hip_multigpu_max_abs(self.h, C.byref(mx), C.byref(bad)), "max_abs")
+        return mx.value, bad.value
+
+    def stats(self, reset=False):
+        out = (C.c_double * 10)()
+        self._check(self.L.fdtd_hip_multigpu_stats(self.h, C.byref(out), 1 if reset else 0), "stats")
+        keys = ("slabs", "pairs", "single_steps", "issue_us_per_op", "wait_us_per_op", "wall_us_per_op", "split",
+                "outer_thirds_first", "thread_per_slab", "shells_follow")
+        return dict(zip(keys, list(out)))
+
+    def close(self):
+        if self.h:
+            self.L.fdtd_hip_multigpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -99,7 +99,8 @@ int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS);
  * cuda_optimized.cu:59-61,261-279,482-499).  Host buffers stay fp32. */
 int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS);
 
-/* The same operator on several GPUs of one node, driven by the calling thread: the x range is cut
+/* The same operator on several GPUs of one node, in one process (one issuing host thread per slab while the
+ * call lasts; see the fdtd_hip_multigpu_* session below, on which it is built): the x range is cut
  * into one slab per device, every pair of time steps ends with a push of 4 ghost planes to each
  * neighbour (hipMemcpyPeerAsync: copy engines over xGMI, no compute units), overlapped with the
  * interior sweep on a second stream.  No counterpart in the reference, which is single-device; the
@@ -340,6 +341,51 @@ int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const floa
                            const float *src_coords, const float *cur, const float *prev, float *next,
                            int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
                            int variant, int x_shift, int global_nx, void *stream);
+
+/* The same decomposition as a session that owns the slabs on the devices, for callers that keep the
+ * wavefield on the GPUs between calls (a 2048^3 grid is 139 GB of host arrays through the operator
+ * above; here nothing of it exists on the host unless it is asked for).  No counterpart in the
+ * reference (single device, main.cpp:53-72 takes host arrays); Kernel_HIP_MultiGPU is create +
+ * set_sources + upload + advance (untimed steps) + advance (timed steps) + gather x 3 + destroy.
+ *   create   geom describes the whole domain (padded extents, y / z ranges, spacings, origin; the x range
+ *            must be the whole extent 0 .. nxp-9: the slabs cover it).  devices[0 .. ndev-1] are HIP device
+ *            numbers, one slab each in this order along x; a device named twice carries two slabs (a
+ *            rehearsal on fewer GPUs).  At least 8 planes per slab.  Allocates four level buffers and m per
+ *            slab ((nx_slab + 8) planes each), three streams and the events of the schedule per slab, and
+ *            starts one issuing thread per slab (FDTD_MULTIGPU_ONE_THREAD, or FDTD_MULTIGPU_THREADS=0 in the
+ *            environment: the calling thread issues for every slab, device after device).
+ *   set_sources  src[src_steps][src_stride], src_coords[coord_rows][coord_stride] (host), sources p_src_m ..
+ *            p_src_M; copied to every device.  p_src_M < p_src_m: no sources.
+ *   fill_standard_inputs  the driver's benchmark inputs (main.cpp:345-356: u = 0, m = 1.5, nsrc Ricker
+ *            sources of nt samples at the positions of main.cpp:301-325) made on the devices; time index 0.
+ *   upload   host u[3][nxp][nyp][nzp] (the reference's ring at time index time_m) and m[nxp][nyp][nzp]
+ *            (NULL: keep the model already there) cut into the slabs.
+ *   advance  steps time_m .. time_M inclusive; time_m must be the time index the session stands at (the
+ *            one given to upload, 0 after fill, time_M + 1 of the previous advance).  Two steps per exchange,
+ *            one single step at the end of an odd count.  Returns when every device has finished;
+ *            timers (may be NULL) ->section0 += wall time of the call.
+ *   gather   one ring slot (0 .. 2; slot t % 3 holds the newest level u(t), t = the session's time index)
+ *            into a host array of nxp*nyp*nzp floats.
+ *   max_abs  max |u| of the newest level and its number of NaN / Inf values, reduced on the devices.
+ *   stats    see fdtd_multigpu.hip: slabs, operations, host issue and wait time per operation, schedule.
+ * Every function returns 0 or a positive hipError_t; after a failed advance the session only accepts
+ * destroy.  Calls on one session must not overlap. */
+typedef struct fdtd_multigpu fdtd_multigpu;
+#define FDTD_MULTIGPU_ONE_THREAD 1   /* issue from the calling thread only */
+#define FDTD_MULTIGPU_NO_OVERLAP 2   /* one chain per slab: no interior / boundary split */
+#define FDTD_MULTIGPU_NO_EXCHANGE 4  /* timing experiment: no pushes, no waits for neighbours; WRONG RESULTS */
+int fdtd_hip_multigpu_create(const struct fdtd_geom *geom, int ndev, const int *devices, int flags,
+                             fdtd_multigpu **out);
+int fdtd_hip_multigpu_destroy(fdtd_multigpu *h);
+int fdtd_hip_multigpu_set_sources(fdtd_multigpu *h, const float *src, int src_steps, int src_stride,
+                                  const float *src_coords, int coord_rows, int coord_stride,
+                                  int p_src_m, int p_src_M);
+int fdtd_hip_multigpu_fill_standard_inputs(fdtd_multigpu *h, int nt, int nsrc);
+int fdtd_hip_multigpu_upload(fdtd_multigpu *h, const float *u, const float *m, int time_m);
+int fdtd_hip_multigpu_advance(fdtd_multigpu *h, int time_m, int time_M, struct profiler *timers);
+int fdtd_hip_multigpu_gather(fdtd_multigpu *h, int ring_slot, float *host_level);
+int fdtd_hip_multigpu_max_abs(fdtd_multigpu *h, float *max_abs, long *nonfinite);
+int fdtd_hip_multigpu_stats(fdtd_multigpu *h, double out[10], int reset);
 
 /* fdtd_hip_two_steps_slab without the work-space argument, for callers that cannot allocate
  * device memory: code under HIP graph capture, tight serving loops, harnesses that forbid
