@@ -62,6 +62,17 @@ def parse_args():
     ap.add_argument("--self-exchange", action="store_true",
                     help="N=1 rehearsal of the N>1 schedule: the rank is its own two neighbours, RCCL messages "
                          "included (measures what the exchange costs next to the interior sweep; not the headline)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "peer", "both"],
+                    help="ghost exchange of the slab runs: rccl = one process per GPU, RCCL point-to-point messages "
+                         "(default); peer = one process, one issuing thread per slab, hipMemcpyPeerAsync pushes on the "
+                         "copy engines (the library's fdtd_hip_multigpu_* session); both = one run of each, the peer "
+                         "run's figures under `exchange_peer`")
+    ap.add_argument("--slabs", type=int, default=0,
+                    help="--transport peer: number of slabs (default --gpus); more slabs than GPUs puts several slabs "
+                         "on a device (a rehearsal of the N-GPU schedule on fewer GPUs)")
+    ap.add_argument("--no-breakdown", action="store_true",
+                    help="--transport peer: skip the two extra runs (no exchange; no exchange and no interior / "
+                         "boundary split) that price the exchange and the schedule")
     ap.add_argument("--velocity", default="constant", choices=["constant", "layered"],
                     help="N=1: m = 1.5 everywhere (the reference's benchmark input, main.cpp:352) or five horizontal "
                          "layers of velocity 1.5 .. 4.5 (m = 1/v^2): same kernels, heterogeneous medium")
@@ -195,8 +206,158 @@ def stats(xs):
     return mean, var ** 0.5
 
 
+def roofline_basic(algo_bytes, launch_cells, kernel_ms, updates_per_launch, kernel_desc):
+    achieved = algo_bytes * launch_cells / (kernel_ms * 1e-3) / 1e9
+    kbytes = 10.0 if updates_per_launch == 2 else 16.0
+    return {
+        "bound": "hbm",
+        "kernel": kernel_desc,
+        "cell_updates_per_launch": launch_cells,
+        "achieved": round(achieved, 1),
+        "achieved_basis": f"{algo_bytes:g} B per cell update (algorithmic, single-step model) x cell updates per launch / kernel time",
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "avg_kernel_ms": round(kernel_ms, 4),
+        "compulsory_bytes_per_launch": kbytes * launch_cells,
+        "compulsory_GBps": round(kbytes * launch_cells / (kernel_ms * 1e-3) / 1e9, 1),
+    }, kbytes
+
+
+def peer_main(args):
+    """One process, the library's multi-device session: slabs on the devices, one issuing thread per slab, ghost
+    planes pushed by the copy engines.  A step is a time step of the whole domain."""
+    # three streams per slab; with HIP's default of 4 hardware queues per process two chains of one slab can land
+    # on one queue and serialise (must be set before the HIP runtime initialises)
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("FDTD_HW_QUEUES", "8")
+    import torch
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    ngpu_visible = torch.cuda.device_count()
+    if ngpu_visible < 1:
+        raise SystemExit("bench.py: no GPU visible")
+    slabs = args.slabs or args.gpus
+    if os.environ.get("FDTD_MULTIGPU_DEVICES"):
+        devices = [int(t) for t in os.environ["FDTD_MULTIGPU_DEVICES"].split(",") if t != ""]
+        slabs = len(devices)
+    else:
+        ndev = min(args.gpus, ngpu_visible)
+        per = (slabs + ndev - 1) // ndev
+        devices = [min(i // per, ndev - 1) for i in range(slabs)]     # neighbouring slabs share a device
+    n = args.grid or (512 if (args.gpus == 1 and slabs == 1) else MULTI_GPU_GRID)
+    NX = n * slabs if args.weak else (args.global_x or n)
+    K, W, R = args.steps, args.warmup, max(1, args.reps)
+    total = K + W
+    g = pkg.Geom(NX + 8, n + 8, n + 8, 0, NX - 1, 0, n - 1, 0, n - 1, 1e-3, 0.1, 0.1, 0.1, 0.0, 0.0, 0.0)
+
+    def run(flags, reps):
+        times, st, mx = [], None, 0.0
+        with pkg.MultiGpuSession(g, devices, flags) as s:
+            for rep in range(reps):
+                s.fill_standard_inputs(total + 1, 1)
+                if W:
+                    s.advance(0, W - 1)
+                s.stats(reset=True)
+                t0 = time.perf_counter()
+                s.advance(W, total - 1)          # returns when every device has finished
+                times.append(time.perf_counter() - t0)
+                st = s.stats()
+            mx, bad = s.max_abs()
+            assert bad == 0 and mx > 0.0, "field is empty or not finite"
+        return times, st, mx
+
+    elapsed_reps, st, _ = run(0, R)
+    mean_s, sd_s = stats(elapsed_reps)
+    cells_per_step = float(NX) * n * n
+    mcells = cells_per_step * K / mean_s / 1e6
+    rates = [cells_per_step * K / e / 1e6 for e in elapsed_reps]
+    ms_step = mean_s / K * 1e3
+    exchange = {
+        "transport": "hipMemcpyPeerAsync pushes on the copy engines, one process",
+        "issuing": "one host thread per slab" if st["thread_per_slab"] else "the calling thread for every slab",
+        "ghost_bytes_per_side_per_step": 4 * (n + 8) * (n + 8) * 4 / 2,
+        "host_issue_us_per_pair": round(st["issue_us_per_op"], 1),
+        "host_wait_for_neighbour_thread_us_per_pair": round(st["wait_us_per_op"], 1),
+        "device_us_per_pair": round(st["wall_us_per_op"], 1),
+        "interior_boundary_split": bool(st["split"]),
+        "outer_thirds_first": bool(st["outer_thirds_first"]),
+    }
+    if not args.no_breakdown and slabs > 1:
+        # what the exchange costs: the same schedule without pushes and without waits for the neighbours (wrong
+        # results, right timing); what the schedule costs: one whole-slab call per pair and slab on top of that
+        t_noex, _, _ = run(pkg.abi.MULTIGPU_NO_EXCHANGE, 1 if R < 3 else 2)
+        t_whole, _, _ = run(pkg.abi.MULTIGPU_NO_EXCHANGE | pkg.abi.MULTIGPU_NO_OVERLAP, 1 if R < 3 else 2)
+        ms_noex, ms_whole = min(t_noex) / K * 1e3, min(t_whole) / K * 1e3
+        t_one, st_one, _ = run(pkg.abi.MULTIGPU_ONE_THREAD, 1 if R < 3 else 2)
+        exchange.update({
+            "exposed_ms_per_step": round(max(0.0, ms_step - ms_noex), 4),
+            "sweep_only_ms_per_step": round(ms_whole, 4),
+            "same_schedule_without_exchange_ms_per_step": round(ms_noex, 4),
+            "schedule_overhead_ms_per_step": round(ms_noex - ms_whole, 4),
+            "one_issuing_thread": {"ms_per_step": round(min(t_one) / K * 1e3, 4),
+                                   "host_issue_us_per_pair": round(st_one["issue_us_per_op"], 1)},
+        })
+    per_dev = max(devices.count(d) for d in set(devices))
+    own_cells = cells_per_step / slabs
+    pair_ms = st["wall_us_per_op"] * 1e-3 / per_dev      # one slab's pair, when the slabs of a device run one after the other
+    roof, kbytes = roofline_basic(ALGO_BYTES_PER_UPDATE, own_cells * 2, pair_ms, 2,
+                                  "all launches of one pair of steps on one slab (interior sweep, boundary zones, seam "
+                                  "passes; wall time per pair / slabs per device)")
+    out = {
+        "metric": "Mcells/s", "value": round(mcells, 1), "unit": "Mcells/s", "n_gpus": args.gpus, "steps": K, "warmup": W,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+        "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "effective_GBps_at_algorithmic_bytes": round(mcells * ALGO_BYTES_PER_UPDATE / 1e3, 1),
+        "reps": {"n": R, "protocol": "each repetition: inputs made on the devices, warm-up steps untimed, then the timed steps",
+                 "ms_per_step_mean": round(ms_step, 4), "ms_per_step_stddev": round(sd_s / K * 1e3, 4),
+                 "Mcells_per_s": [round(r, 1) for r in rates], "Mcells_per_s_stddev": round(stats(rates)[1], 1)},
+        "config": {"workload": f"{NX}x{n}x{n} fp32 as {slabs} x-slabs on {len(set(devices))} GPU(s) (devices {devices}), two steps "
+                               f"per sweep and exchange (4 ghost planes of u(t+2) per side) pushed with hipMemcpyPeerAsync, "
+                               f"{total} steps ({W} untimed)"
+                               + (" [several slabs per GPU: schedule rehearsal]" if per_dev > 1 else ""),
+                   "variant": "auto", "algorithmic_bytes_per_cell_update": ALGO_BYTES_PER_UPDATE,
+                   "kernel_bytes_per_cell_update": kbytes, "ranks": 1, "slabs": slabs},
+        "roofline": roof,
+        "exchange": exchange,
+        "library_source_hash": library_source_hash(),
+    }
+    print(json.dumps(out))
+    return 0
+
+
+def run_both(args):
+    """--transport both: the RCCL run, then the peer run in a process of its own; one line, the peer run's figures
+    under `exchange_peer`."""
+    def child(transport):
+        argv = [a for a in sys.argv[1:]]
+        for i, a in enumerate(argv):
+            if a == "--transport":
+                argv[i + 1] = transport
+            elif a.startswith("--transport="):
+                argv[i] = "--transport=" + transport
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, stdout=subprocess.PIPE)
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            raise SystemExit(f"bench.py: the --transport {transport} run failed (exit code {p.returncode})")
+        return json.loads(lines[-1])
+    rccl = child("rccl")
+    peer = child("peer")
+    rccl["exchange_peer"] = dict(peer.get("exchange", {}), value=peer["value"], ms_per_step=peer["ms_per_step"],
+                                 workload=peer["config"]["workload"])
+    print(json.dumps(rccl))
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.transport == "both":
+        sys.exit(run_both(args))
+    if args.transport == "peer":
+        if int(os.environ.get("RANK", "0")) != 0:
+            return          # under a launcher: rank 0 drives every device, the other ranks have nothing to do
+        sys.exit(peer_main(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
