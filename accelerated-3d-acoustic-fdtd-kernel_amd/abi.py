@@ -150,6 +150,10 @@ def lib():
     L.fdtd_hip_source_inject_slab.restype = C.c_int
     L.fdtd_hip_two_steps.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 6 + [C.c_void_p]
     L.fdtd_hip_two_steps.restype = C.c_int
+    L.fdtd_hip_two_steps_damped.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 8 + [C.c_int] * 7 + [C.c_void_p]
+    L.fdtd_hip_two_steps_damped.restype = C.c_int
+    L.fdtd_hip_forward_last_call_fused.argtypes = []
+    L.fdtd_hip_forward_last_call_fused.restype = C.c_int
     L.fdtd_hip_two_steps_ex.argtypes = [C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p] * 3
     L.fdtd_hip_two_steps_ex.restype = C.c_int
     L.fdtd_hip_two_steps_slab.argtypes = ([C.POINTER(Geom)] + [C.c_void_p] * 7 + [C.c_int] * 9

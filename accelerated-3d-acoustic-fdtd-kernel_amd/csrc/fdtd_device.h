@@ -97,4 +97,4 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
                         int variant, int flags, int x_shift, int global_nx, void *stream, hipEvent_t ev_begin,
-                        hipEvent_t ev_end, float *scratch, long scratch_floats);
+                        hipEvent_t ev_end, float *scratch, long scratch_floats, const float *damp = nullptr);

@@ -52,6 +52,8 @@ __global__ __launch_bounds__(256) void receiver_kernel(ReceiverArgs a) {
   a.rec_row[p] = sum;
 }
 
+int g_forward_last_fused = 0;   // did the last Kernel_HIP_Forward call take two steps per sweep?
+
 struct Buffers {
   std::vector<void *> p;
   ~Buffers() {
@@ -182,23 +184,93 @@ extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_ve
   } guard{ev};
   for (hipEvent_t &e : ev) FDTD_HIP_CHECK(hipEventCreate(&e));
   hipStream_t s = nullptr;
-  for (int time = time_m; time <= time_M; ++time) {
-    const int t0 = ((time % 3) + 3) % 3, t1 = (((time + 2) % 3) + 3) % 3, t2 = (((time + 1) % 3) + 3) % 3;
-    const int k = (n_timed > 0 && time >= first_timed) ? time - first_timed : -1;
-    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3], s));
-    if ((rc = fdtd_hip_stencil_step_damped_order(&g, d_m, d_damp, d_u, t0, t1, t2, order, s))) return rc;
-    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 1], s));
-    if (has_src &&
-        (rc = fdtd_hip_source_inject_order(&g, d_m, d_src, d_sc, d_u, t2, time, p_src_m, p_src_M, src_vec->size[1],
-                                           src_coords_vec->size[1], order, s)))
-      return rc;
-    if (has_rec && (rc = fdtd_hip_receiver_sample_order(&g, d_u, t0, d_rc, d_rec, time, p_rec_m, p_rec_M, rec_vec->size[1],
-                                                        rec_coords_vec->size[1], order, s)))
-      return rc;
-    if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 2], s));
+  const int src_stride = has_src ? src_vec->size[1] : 1, sc_stride = has_src ? src_coords_vec->size[1] : 3;
+  const int rec_stride = has_rec ? rec_vec->size[1] : 1, rc_stride = has_rec ? rec_coords_vec->size[1] : 3;
+  auto mod3 = [](int t) { return ((t % 3) + 3) % 3; };
+  int n_units = 0;   // timed units: steps, or pairs of steps
+
+  // Order 4, boxes the two-step sweep is made for (16 M cells and more, rows of whole float4s): two damped
+  // steps per sweep (fdtd_march2.hip with the damping field as a sixth stream: 12 instead of 20 bytes per
+  // cell update).  Four level buffers rotate as in the operators' time loop: a level written over the slot
+  // of u(t-1) in the reference's ring inherits that slot's halo, so the shell of prev is copied into the
+  // buffer that receives u(t+2) before every pair unless all shells are the same and no source corner
+  // reaches the halo layer.  Receivers sample u(time) and u(time+1) behind the sweep: u(time+1) is
+  // complete in memory then, first scatter included.
+  const char *fe = getenv("FDTD_FUSE2");
+  const bool fuse = order == FDTD_STENCIL_ORDER && time_M - time_m + 1 >= 4 && (!fe || atoi(fe) != 0) &&
+                    fdtd_march2_preferred(&g) &&
+                    fdtd_march2_eligible(&g, d_m, d_u, d_u + vol, d_u + 2 * vol, d_damp, has_src ? p_src_M - p_src_m + 1 : 0);
+  g_forward_last_fused = fuse ? 1 : 0;
+  if (fuse) {
+    float *d_extra = nullptr;
+    if ((rc = buf.alloc((void **)&d_extra, vol * sizeof(float)))) return rc;
+    // the fourth buffer starts as a copy of a ring slot: same padding beyond the shell as the caller's arrays
+    FDTD_HIP_CHECK(hipMemcpyAsync(d_extra, d_u, vol * sizeof(float), hipMemcpyDeviceToDevice, s));
+    float *P[4] = {d_u, d_u + vol, d_u + 2 * vol, d_extra};
+    const bool sources_inside =
+        !has_src || fdtd_host_sources_inside((const float *)src_coords_vec->data, sc_stride, p_src_m, p_src_M, g);
+    const bool follow = !sources_inside || !fdtd_host_shells_identical((const float *)u_vec->data, vol, g);
+    int cur = mod3(time_m), prev = mod3(time_m + 2), third = mod3(time_m + 1), spare = 3;
+    auto sample = [&](const float *level, int time) {
+      return has_rec ? fdtd_hip_receiver_sample_order(&g, level, 0, d_rc, d_rec, time, p_rec_m, p_rec_M, rec_stride,
+                                                      rc_stride, order, s)
+                     : 0;
+    };
+    int time = time_m;
+    while (time <= time_M) {
+      const bool timed = n_timed > 0 && time >= first_timed;
+      // a pair must not straddle the start of the timed window
+      const bool pair = time + 1 <= time_M && !(n_timed > 0 && time < first_timed && time + 1 >= first_timed);
+      const int k = timed ? n_units : -1;
+      if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3], s));
+      if (pair) {
+        if (follow && (rc = fdtd_hip_copy_shell(&g, P[spare], P[prev], 0, s))) return rc;
+        rc = fdtd_two_steps_impl(&g, d_m, d_src, d_sc, P[cur], P[prev], P[third], P[spare], time, has_src ? p_src_m : 0,
+                                 has_src ? p_src_M : -1, src_stride, sc_stride, FDTD_VARIANT_AUTO, sources_inside ? 1 : 0,
+                                 0, 0, s, nullptr, nullptr, nullptr, 0, d_damp);
+        if (rc) return rc;
+        if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 1], s));
+        if ((rc = sample(P[cur], time)) || (rc = sample(P[third], time + 1))) return rc;
+        const int ncur = spare, nprev = third, nthird = cur, nspare = prev;
+        cur = ncur; prev = nprev; third = nthird; spare = nspare;
+        time += 2;
+      } else {
+        if ((rc = fdtd_stencil_levels_damped(&g, d_m, d_damp, P[cur], P[prev], P[third], order, s))) return rc;
+        if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 1], s));
+        if (has_src && (rc = fdtd_inject_level(&g, d_m, d_src, d_sc, P[third], time, p_src_m, p_src_M, src_stride,
+                                               sc_stride, 0, g.x_m - 1, g.x_M + 1, 0, 0, 0, s)))
+          return rc;
+        if ((rc = sample(P[cur], time))) return rc;
+        const int ncur = third, nprev = cur, nthird = prev;
+        cur = ncur; prev = nprev; third = nthird;
+        time += 1;
+      }
+      if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 2], s));
+      if (timed) ++n_units;
+    }
+    // u(T+1), u(T), u(T-1) go where the reference's ring leaves them
+    const int pos[3] = {cur, prev, third};
+    const int tgt[3] = {mod3(time_M + 1), mod3(time_M), mod3(time_M + 2)};
+    if ((rc = fdtd_ring_settle(&g, P, pos, spare, tgt, s))) return rc;
+  } else {
+    for (int time = time_m; time <= time_M; ++time) {
+      const int t0 = mod3(time), t1 = mod3(time + 2), t2 = mod3(time + 1);
+      const int k = (n_timed > 0 && time >= first_timed) ? time - first_timed : -1;
+      if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3], s));
+      if ((rc = fdtd_hip_stencil_step_damped_order(&g, d_m, d_damp, d_u, t0, t1, t2, order, s))) return rc;
+      if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 1], s));
+      if (has_src && (rc = fdtd_hip_source_inject_order(&g, d_m, d_src, d_sc, d_u, t2, time, p_src_m, p_src_M, src_stride,
+                                                        sc_stride, order, s)))
+        return rc;
+      if (has_rec &&
+          (rc = fdtd_hip_receiver_sample_order(&g, d_u, t0, d_rc, d_rec, time, p_rec_m, p_rec_M, rec_stride, rc_stride, order, s)))
+        return rc;
+      if (k >= 0) FDTD_HIP_CHECK(hipEventRecord(ev[(size_t)k * 3 + 2], s));
+    }
+    n_units = n_timed;
   }
   FDTD_HIP_CHECK(hipStreamSynchronize(s));
-  for (int k = 0; k < n_timed; ++k) {
+  for (int k = 0; k < n_units; ++k) {
     float a = 0.f, b = 0.f;
     FDTD_HIP_CHECK(hipEventElapsedTime(&a, ev[(size_t)k * 3], ev[(size_t)k * 3 + 1]));
     FDTD_HIP_CHECK(hipEventElapsedTime(&b, ev[(size_t)k * 3 + 1], ev[(size_t)k * 3 + 2]));
@@ -209,3 +281,6 @@ extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_ve
   if (has_rec) FDTD_HIP_CHECK(hipMemcpy(rec_vec->data, d_rec, n_rec * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
+
+// 1 when the last Kernel_HIP_Forward call ran two steps per sweep, 0 when it ran one sweep per step.
+extern "C" int fdtd_hip_forward_last_call_fused(void) { return g_forward_last_fused; }

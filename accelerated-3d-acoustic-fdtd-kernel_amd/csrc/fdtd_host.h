@@ -1,6 +1,7 @@
 // fdtd_host.h — host-side helpers shared by the operator wrappers (fdtd_operators.hip) and the
 // multi-device operator (fdtd_multigpu.hip).
 #pragma once
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -13,6 +14,62 @@
 // Shape checks of the operators' arguments (fdtd_operators.hip): 0 or hipErrorInvalidValue.
 int fdtd_check_operator_args(const dataobj *m_vec, const dataobj *src_vec, const dataobj *coords_vec,
                              const dataobj *u_vec, int p_src_M, int p_src_m);
+
+// Do the three ring levels of a host array u[3][nxp][nyp][nzp] carry bit-identical shells (the two layers of
+// cells around the updated box)?  Then no shell has to follow the ring when four level buffers rotate.
+inline bool fdtd_host_shells_identical(const float *u, size_t vol, const fdtd_geom &g) {
+  const long sx = (long)g.nyp * g.nzp, sy = g.nzp;
+  const int ez = g.z_M - g.z_m + 1;
+  for (int x = g.x_m - 2; x <= g.x_M + 2; ++x)
+    for (int y = g.y_m - 2; y <= g.y_M + 2; ++y) {
+      const bool whole = x < g.x_m || x > g.x_M || y < g.y_m || y > g.y_M;
+      const long row = (long)(x + FDTD_HALO) * sx + (long)(y + FDTD_HALO) * sy + FDTD_HALO + g.z_m - 2;
+      for (int l = 1; l < 3; ++l) {
+        const float *a = u + row, *b = u + (size_t)l * vol + row;
+        if (whole) {
+          if (memcmp(a, b, (size_t)(ez + 4) * sizeof(float))) return false;
+        } else if (memcmp(a, b, 2 * sizeof(float)) || memcmp(a + ez + 2, b + ez + 2, 2 * sizeof(float))) {
+          return false;
+        }
+      }
+    }
+  return true;
+}
+
+// Can a corner of the sources p_src_m .. p_src_M land in the halo layer of the box?  (Positions as
+// openacc.cpp:185-187 computes them; coords is a host array.)
+inline bool fdtd_host_sources_inside(const float *coords, int coord_stride, int p_src_m, int p_src_M, const fdtd_geom &g) {
+  for (int p = p_src_m; p <= p_src_M; ++p) {
+    const int posx = (int)floorf((-g.o_x + coords[(size_t)p * coord_stride + 0]) / g.h_x);
+    const int posy = (int)floorf((-g.o_y + coords[(size_t)p * coord_stride + 1]) / g.h_y);
+    const int posz = (int)floorf((-g.o_z + coords[(size_t)p * coord_stride + 2]) / g.h_z);
+    if (posx < g.x_m || posx + 1 > g.x_M || posy < g.y_m || posy + 1 > g.y_M || posz < g.z_m || posz + 1 > g.z_M)
+      return false;
+  }
+  return true;
+}
+
+// Four rotating level buffers back into ring order: the levels at pos[0 .. 2] go to the buffers tgt[0 .. 2]
+// (indices into P), each with its box and shell (fdtd_hip_copy_shell), through the free buffer.
+inline int fdtd_ring_settle(const fdtd_geom *g, float *const P[4], const int pos_in[3], int free_pos, const int tgt[3],
+                            void *stream) {
+  int pos[3] = {pos_in[0], pos_in[1], pos_in[2]};
+  for (int it = 0; it < 8; ++it) {
+    int mover = -1;
+    for (int r = 0; r < 3; ++r)
+      if (pos[r] != tgt[r] && tgt[r] == free_pos) mover = r;
+    if (mover < 0)
+      for (int r = 0; r < 3; ++r)
+        if (pos[r] != tgt[r]) mover = r;
+    if (mover < 0) break;
+    const int rc = fdtd_hip_copy_shell(g, P[free_pos], P[pos[mover]], 1, stream);
+    if (rc) return rc;
+    const int old = pos[mover];
+    pos[mover] = free_pos;
+    free_pos = old;
+  }
+  return 0;
+}
 
 // Transfers between the caller's pageable arrays and the device.  A plain hipMemcpy of pageable
 // memory runs at 27 GB/s towards the device and 17 GB/s back on an MI355X host, and the caller's

@@ -55,10 +55,11 @@ constexpr int M2_ROWS = 8;        // output rows per tile
 constexpr int M2_ZCELLS = 512;    // z extent
 constexpr int M2_MAX_SRC = 8;     // 8 corners each: one lane per corner
 
-struct Coef2 { float cm2, cm1, c0, dt2, r1, r2, r3, r4, neg2r1; };
+struct Coef2 { float cm2, cm1, c0, dt2, r1, r2, r3, r4, neg2r1, dt, r0; };   // dt, r0 = 1/dt: damped form only
 
 struct March2Args {
   const char *B, *A, *m;
+  const char *damp;   // damping field of the shape of m (DAMP instantiations), else unused
   char *C, *D;
   long sx;            // cells per plane
   int sy;             // cells per row
@@ -114,25 +115,36 @@ __device__ __forceinline__ void st4(rsrc_t r, int soff, unsigned voff, f32x4 v) 
 // members of a pair.  Per cell: the operations, order and rounding of openacc.cpp:159-164.
 __device__ __forceinline__ f32x2 lo2(f32x4 v) { return f32x2{v.x, v.y}; }
 __device__ __forceinline__ f32x2 hi2(f32x4 v) { return f32x2{v.z, v.w}; }
+// DAMP: the update with an absorbing sponge (fdtd_forward.hip; no reference arithmetic, parity unpinned):
+//     u+ = dt^2 ( lap - (-2 r1 u + r1 u-) m + r0 damp u ) / (m + dt damp),   dc = damp at the cell
+template <bool DAMP = false>
 __device__ __forceinline__ f32x2 update_pair(const Coef2 &k, f32x2 uc, f32x2 xm2, f32x2 xm1, f32x2 xp1, f32x2 xp2,
                                              f32x2 ym2, f32x2 ym1, f32x2 yp1, f32x2 yp2, f32x2 zs2, f32x2 zs1, f32x2 up,
-                                             f32x2 mc) {
+                                             f32x2 mc, f32x2 dc = f32x2{0, 0}) {
   // zs2 = u(z-2) + u(z+2), zs1 = u(z-1) + u(z+1)
   const f32x2 r5 = k.c0 * uc;
   const f32x2 dxx = r5 + k.cm2 * (xm2 + xp2) + k.cm1 * (xm1 + xp1);
   const f32x2 dyy = r5 + k.cm2 * (ym2 + yp2) + k.cm1 * (ym1 + yp1);
   const f32x2 dzz = r5 + k.cm2 * zs2 + k.cm1 * zs1;
-  const f32x2 num = k.dt2 * (k.r2 * dxx + k.r3 * dyy + k.r4 * dzz - (k.neg2r1 * uc + k.r1 * up) * mc);
-  return f32x2{num.x / mc.x, num.y / mc.y};
+  if constexpr (DAMP) {
+    const f32x2 num = k.dt2 * (k.r2 * dxx + k.r3 * dyy + k.r4 * dzz - (k.neg2r1 * uc + k.r1 * up) * mc + k.r0 * dc * uc);
+    const f32x2 den = mc + k.dt * dc;
+    return f32x2{num.x / den.x, num.y / den.y};
+  } else {
+    const f32x2 num = k.dt2 * (k.r2 * dxx + k.r3 * dyy + k.r4 * dzz - (k.neg2r1 * uc + k.r1 * up) * mc);
+    return f32x2{num.x / mc.x, num.y / mc.y};
+  }
 }
 // edge_r: this lane's right neighbours are eR even though it is not lane 63 (the last lane of a row
 // that ends inside the wave, or of a row part that is a half-wave).  edge_l: its left neighbours are eL
 // even though it is not lane 0 (the first lane of the second half-wave).  offer: what this lane shows
 // the lane before it as cells 0 and 1 (its own c.x, c.y, except in the lane behind a row that ends on
 // the first lane of a row part).
+template <bool DAMP = false>
 __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, f32x4 xm1, f32x4 xp1, f32x4 xp2,
                                             f32x4 ym2, f32x4 ym1, f32x4 yp1, f32x4 yp2, f32x2 eL, f32x2 eR, f32x4 up,
-                                            f32x4 mc, bool edge_r, f32x2 offer, bool edge_l = false) {
+                                            f32x4 mc, bool edge_r, f32x2 offer, bool edge_l = false,
+                                            f32x4 dc = f32x4{0, 0, 0, 0}) {
   f32x2 l = f32x2{dpp_prev(eL.x, c.z), dpp_prev(eL.y, c.w)};         // cells z-2, z-1 of cell 0
   f32x2 r = f32x2{dpp_next(eR.x, offer.x), dpp_next(eR.y, offer.y)}; // cells z+1, z+2 of cell 3
   l = edge_l ? eL : l;
@@ -142,10 +154,10 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
   // cells 2,3: z-2: (c.x, c.y)  z+2: (r.x, r.y)   z-1: (c.y, c.z)  z+1: (c.w, r.x)
   const f32x2 zs2_lo = l + ch, zs2_hi = cl + r;
   const f32x2 zs1_lo = f32x2{l.y + c.y, c.x + c.z}, zs1_hi = f32x2{c.y + c.w, c.z + r.x};
-  const f32x2 olo = update_pair(k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1), lo2(yp2),
-                                zs2_lo, zs1_lo, lo2(up), lo2(mc));
-  const f32x2 ohi = update_pair(k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1), hi2(yp2),
-                                zs2_hi, zs1_hi, hi2(up), hi2(mc));
+  const f32x2 olo = update_pair<DAMP>(k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1),
+                                      lo2(yp2), zs2_lo, zs1_lo, lo2(up), lo2(mc), lo2(dc));
+  const f32x2 ohi = update_pair<DAMP>(k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1),
+                                      hi2(yp2), zs2_hi, zs1_hi, hi2(up), hi2(mc), hi2(dc));
   return f32x4{olo.x, olo.y, ohi.x, ohi.y};
 }
 
@@ -169,7 +181,7 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // serve the seam pass).  The kernels below map workgroups to tiles.
 typedef f32x4 (&BbufRef)[2][16][128];
 typedef f32x4 (&CringRef)[3][12][128];
-template <bool NT, int ZH, bool MASK, int LPR>
+template <bool NT, int ZH, bool MASK, int LPR, bool DAMP>
 __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int zb, bool cut_l, bool cut_r, int yt,
                                             int xc, BbufRef Bbuf, CringRef Cring) {
   static_assert(LPR == 64 || (LPR == 32 && ZH == 1), "half-wave tiles exist for rows of 128 cells only");
@@ -250,6 +262,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   const long base = (long)(p0 - 2 + FDTD_HALO) * a.sx * 4;
   const rsrc_t rB = make_rsrc(a.B + base, 0xffffffffu), rA = make_rsrc(a.A + base, 0xffffffffu);
   const rsrc_t rM = make_rsrc(a.m + base, 0xffffffffu);
+  const rsrc_t rDm = make_rsrc((DAMP ? a.damp : a.m) + base, 0xffffffffu);   // damping field
   const rsrc_t rC = make_rsrc(a.C + base, 0xffffffffu), rD = make_rsrc(a.D + base, 0xffffffffu);
   int sp = 2 * sxb;   // byte offset of plane p
 
@@ -307,6 +320,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   f32x4 cc[5][2];     // C planes p-4 .. p-1 and the new plane p (output rows)
   f32x4 mh[2][2];     // m planes p-2, p-1 (output rows)
   f32x4 av[3], mv[3]; // A, m of plane p
+  f32x4 dv[DAMP ? 3 : 1], dh[2][DAMP ? 2 : 1];   // DAMP: the damping field of plane p, and of planes p-2, p-1 (output rows)
   f32x2 be[3];        // z-edge cells of B, plane p
   f32x4 bh, bh2;      // B row outside the stack, planes p+1 and p+2 (fetched when the neighbouring tile
                       // fetches the same row as one of its own: plane p+3)
@@ -327,6 +341,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
       }
     }
     mv[s] = s == 0 ? LD4S(rM, sp + rowoff[s], vzs[s]) : LD4(rM, sp + rowoff[s], vzs[s]);
+    if constexpr (DAMP) dv[s] = s == 0 ? LD4S(rDm, sp + rowoff[s], vzs[s]) : LD4(rDm, sp + rowoff[s], vzs[s]);
     be[s] = LD2(rB, sp + rowoff[s], vzes[s]);
   }
 #pragma unroll
@@ -334,6 +349,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
 #pragma unroll
     for (int i = 0; i < 5; ++i) cc[i][s] = f32x4{0, 0, 0, 0};
     mh[0][s] = mh[1][s] = f32x4{1, 1, 1, 1};
+    if constexpr (DAMP) dh[0][s] = dh[1][s] = f32x4{0, 0, 0, 0};
     ce[s] = f32x2{0, 0};
   }
   bh = LD4(rB, (sp + sxb) + rowoff_h, vzh);
@@ -377,8 +393,8 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
       if (plane_inside) {
         const f32x4 ym2 = Bbuf[buf][r][lc], ym1 = Bbuf[buf][r + 1][lc];
         const f32x4 yp1 = Bbuf[buf][r + 3][lc], yp2 = Bbuf[buf][r + 4][lc];
-        cnew = update_seg(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s], av[s],
-                          mv[s], sel_r, lo2(PB(2)[s]), sel_l);
+        cnew = update_seg<DAMP>(k, PB(2)[s], PB(0)[s], PB(1)[s], PB(3)[s], PB(4)[s], ym2, ym1, yp1, yp2, be[s], be[s],
+                                av[s], mv[s], sel_r, lo2(PB(2)[s]), sel_l, dv[DAMP ? s : 0]);
         if constexpr (s == 2) cnew = seg2_outside ? ch : cnew;
         if constexpr (MASK && s < 2) cnew = (s == 0 ? out0 : out1) ? av[s] : cnew;
         if (cmask) scatter_into(cnew, cmask, cval, yrow[s]);
@@ -406,8 +422,9 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
             if (h) eL = f32x2{nb.z, nb.w};
             else if (!row_ends_here) eR = f32x2{nb.x, nb.y};
           }
-          f32x4 o = update_seg(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
-                               PB(0)[s], mh[0][s], sel_r, offers_halo ? ce[s] : lo2(PC(2)[s]), sel_l);
+          f32x4 o = update_seg<DAMP>(k, PC(2)[s], PC(0)[s], PC(1)[s], PC(3)[s], cnew, ym2, ym1, yp1, yp2, eL, eR,
+                                     PB(0)[s], mh[0][s], sel_r, offers_halo ? ce[s] : lo2(PC(2)[s]), sel_l,
+                                     dh[0][DAMP ? s : 0]);
           if (dmask) scatter_into(o, dmask, cval2, yrow[s]);
           if (!row_out) {
             if (lane_valid) st4<NT>(rD, (sp - 2 * sxb) + rowoff[s], vzs[s], o);
@@ -423,6 +440,10 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
         }
         mh[0][s] = mh[1][s];
         mh[1][s] = mv[s];
+        if constexpr (DAMP) {
+          dh[0][s] = dh[1][s];
+          dh[1][s] = dv[s];
+        }
       }
     };
     // advance the B ring of a segment and reload what plane p+1 needs
@@ -452,6 +473,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
         }
       }
       mv[s] = s == 0 ? LD4S(rM, sq + rowoff[s], vzs[s]) : LD4(rM, sq + rowoff[s], vzs[s]);
+      if constexpr (DAMP) dv[s] = s == 0 ? LD4S(rDm, sq + rowoff[s], vzs[s]) : LD4(rDm, sq + rowoff[s], vzs[s]);
       be[s] = LD2(rB, sq + rowoff[s], vzes[s]);
     };
     using S0 = std::integral_constant<int, 0>;
@@ -498,14 +520,14 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
 
 // Uniform tiling: every z-tile of the same kind; tile index = z-tile fastest (the tiles on either side of a
 // z-cut read each other's edge cells and should share an L2), then y-tile, then x-chunk.
-template <bool NT, int ZH, bool MASK, int LPR = 64>
+template <bool NT, int ZH, bool MASK, int LPR = 64, bool DAMP = false>
 __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int xchunk, int nyt, int nzt, int wg_base) {
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
   constexpr int TILE_CELLS = ZH == 2 ? M2_ZCELLS : LPR * 4;
   const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
-  march2_tile<NT, ZH, MASK, LPR>(a, xchunk, a.z_m + zt * TILE_CELLS, zt > 0, zt < nzt - 1, yt, xc, Bbuf, Cring);
+  march2_tile<NT, ZH, MASK, LPR, DAMP>(a, xchunk, a.z_m + zt * TILE_CELLS, zt > 0, zt < nzt - 1, yt, xc, Bbuf, Cring);
 }
 
 // Mixed tiling: a row is covered by z-tiles of different kinds — tiles of 512 cells first, then one of 256,
@@ -521,7 +543,7 @@ struct MixedTiling {
   int slots;             // workgroups per band
   int nbands;
 };
-template <bool NT, bool MASK>
+template <bool NT, bool MASK, bool DAMP = false>
 __global__ __launch_bounds__(512) void stencil_march2_mixed_kernel(March2Args a, int xchunk, MixedTiling mt, int wg_base) {
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
@@ -540,9 +562,9 @@ __global__ __launch_bounds__(512) void stencil_march2_mixed_kernel(March2Args a,
   const bool cut_l = zi > 0, cut_r = zi < mt.ntiles - 1;
   const int yt = band * (4 >> kind) + s;        // y-tile index in units of this kind's rows per workgroup
   if (MASK && a.y_m + yt * (M2_ROWS << kind) > a.y_M) return;   // a workgroup wholly beyond the last row (last band)
-  if (kind == 0) march2_tile<NT, 2, MASK, 64>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
-  else if (kind == 1) march2_tile<NT, 1, MASK, 64>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
-  else march2_tile<NT, 1, MASK, 32>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+  if (kind == 0) march2_tile<NT, 2, MASK, 64, DAMP>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+  else if (kind == 1) march2_tile<NT, 1, MASK, 64, DAMP>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+  else march2_tile<NT, 1, MASK, 32, DAMP>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
 }
 
 // D on the four cells around every z-cut of the sweep above (cells cut-2 .. cut+1), from the C
@@ -552,7 +574,7 @@ __global__ __launch_bounds__(512) void stencil_march2_mixed_kernel(March2Args a,
 // 256 rows per workgroup, grid (row groups, cuts, planes).  (A version that marched along x with
 // the centre row in registers moved half the bytes and was no faster: the accesses are 8 KB apart.)
 struct SeamArgs {
-  const float *C, *B, *m;
+  const float *C, *B, *m, *damp;
   float *D;
   long sx;
   int sy, x_m, y_m, y_M, z_m;
@@ -560,6 +582,7 @@ struct SeamArgs {
   Coef2 k;
 };
 struct __attribute__((packed, aligned(4))) Quad { float v[4]; };
+template <bool DAMP>
 __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
   const int y = a.y_m + (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (y > a.y_M) return;
@@ -574,13 +597,14 @@ __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
   const f32x4 xm2 = ld(a.C, i - 2 * a.sx), xm1 = ld(a.C, i - a.sx), xp1 = ld(a.C, i + a.sx), xp2 = ld(a.C, i + 2 * a.sx);
   const f32x4 ym2 = ld(a.C, i - 2 * a.sy), ym1 = ld(a.C, i - a.sy), yp1 = ld(a.C, i + a.sy), yp2 = ld(a.C, i + 2 * a.sy);
   const f32x4 up = ld(a.B, i), mc = ld(a.m, i);
+  const f32x4 dc = DAMP ? ld(a.damp, i) : f32x4{0, 0, 0, 0};
   const f32x2 cl = lo2(c), ch = hi2(c);
   // cells 0,1: z-2: zm  z+2: ch   z-1: (zm.y, c.x)  z+1: (c.y, c.z)
   // cells 2,3: z-2: cl  z+2: zp   z-1: (c.y, c.z)   z+1: (c.w, zp.x)
-  const f32x2 o0 = update_pair(a.k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1), lo2(yp2),
-                               zm + ch, f32x2{zm.y + c.y, c.x + c.z}, lo2(up), lo2(mc));
-  const f32x2 o1 = update_pair(a.k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1), hi2(yp2),
-                               cl + zp, f32x2{c.y + c.w, c.z + zp.x}, hi2(up), hi2(mc));
+  const f32x2 o0 = update_pair<DAMP>(a.k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1),
+                                     lo2(yp2), zm + ch, f32x2{zm.y + c.y, c.x + c.z}, lo2(up), lo2(mc), lo2(dc));
+  const f32x2 o1 = update_pair<DAMP>(a.k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1),
+                                     hi2(yp2), cl + zp, f32x2{c.y + c.w, c.z + zp.x}, hi2(up), hi2(mc), hi2(dc));
   Quad o;
   o.v[0] = o0.x; o.v[1] = o0.y; o.v[2] = o1.x; o.v[3] = o1.y;
   *(Quad *)(a.D + i) = o;
@@ -593,7 +617,7 @@ __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
 // pass; recomputing a cell twice gives the same bits).  The second scatter follows as a launch of
 // its own.  One thread per (corner, star cell).
 struct RepairArgs {
-  const float *C, *B, *m, *coords;
+  const float *C, *B, *m, *coords, *damp;
   float *D;
   long sx;
   int sy, x_m, x_M, y_m, y_M, z_m, z_M;
@@ -603,6 +627,7 @@ struct RepairArgs {
   float h_x, h_y, h_z, o_x, o_y, o_z;
   Coef2 k;
 };
+template <bool DAMP>
 __global__ __launch_bounds__(256) void repair_kernel(RepairArgs a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= a.nsrc * 8 * 13) return;
@@ -622,9 +647,10 @@ __global__ __launch_bounds__(256) void repair_kernel(RepairArgs a) {
   const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (z + FDTD_HALO);
   auto two = [](float v) { return f32x2{v, v}; };
   const float *C = a.C;
-  const f32x2 o = update_pair(a.k, two(C[i]), two(C[i - 2 * a.sx]), two(C[i - a.sx]), two(C[i + a.sx]), two(C[i + 2 * a.sx]),
-                              two(C[i - 2 * a.sy]), two(C[i - a.sy]), two(C[i + a.sy]), two(C[i + 2 * a.sy]),
-                              two(C[i - 2] + C[i + 2]), two(C[i - 1] + C[i + 1]), two(a.B[i]), two(a.m[i]));
+  const f32x2 o = update_pair<DAMP>(a.k, two(C[i]), two(C[i - 2 * a.sx]), two(C[i - a.sx]), two(C[i + a.sx]),
+                                    two(C[i + 2 * a.sx]), two(C[i - 2 * a.sy]), two(C[i - a.sy]), two(C[i + a.sy]),
+                                    two(C[i + 2 * a.sy]), two(C[i - 2] + C[i + 2]), two(C[i - 1] + C[i + 1]), two(a.B[i]),
+                                    two(a.m[i]), two(DAMP ? a.damp[i] : 0.0F));
   a.D[i] = o.x;
 }
 
@@ -849,7 +875,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
                         const float *src_coords, const float *cur, const float *prev, float *next1,
                         float *next2, int time, int p_src_m, int p_src_M, int src_stride, int coord_stride,
                         int variant, int flags, int x_shift, int global_nx, void *stream, hipEvent_t ev_begin,
-                        hipEvent_t ev_end, float *scratch, long scratch_floats) {
+                        hipEvent_t ev_end, float *scratch, long scratch_floats, const float *damp) {
   if (!g || !m || !cur || !prev || !next1 || !next2) return (int)hipErrorInvalidValue;
   {  // the two written levels must not overlap each other or anything that is read
     const size_t vol = (size_t)g->nxp * g->nyp * g->nzp;
@@ -857,7 +883,13 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     if (overlap(next1, next2) || overlap(next1, cur) || overlap(next1, prev) || overlap(next1, m) ||
         overlap(next2, cur) || overlap(next2, prev) || overlap(next2, m))
       return (int)hipErrorInvalidValue;
+    if (damp && (overlap(next1, damp) || overlap(next2, damp))) return (int)hipErrorInvalidValue;
   }
+  // one sweep of the single-step kernels, with the damping term when there is a damping field
+  auto sweep = [&](const fdtd_geom *gg, const float *u0, const float *u1, float *u2, int v) {
+    return damp ? fdtd_stencil_levels_damped(gg, m, damp, u0, u1, u2, FDTD_STENCIL_ORDER, stream)
+                : fdtd_stencil_levels(gg, m, u0, u1, u2, v, stream);
+  };
   const bool has_src = p_src_M >= p_src_m;
   if (has_src && (!src || !src_coords || coord_stride < 3 || src_stride < 1)) return (int)hipErrorInvalidValue;
   const int nsrc = has_src ? p_src_M - p_src_m + 1 : 0;
@@ -921,7 +953,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   const bool sides_in_memory = (g->x_m == dx_m || (flags & 4)) && (g->x_M == dx_M || (flags & 8));
   const bool fuse = (variant == FDTD_VARIANT_AUTO || variant == FDTD_VARIANT_MARCH2) &&
                     env_int2("FDTD_FUSE2", 1) != 0 && offsets_ok && !(many && !sides_in_memory) &&
-                    fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) &&
+                    fdtd_march2_eligible(g, m, cur, prev, next1, next2, nsrc) && ((uintptr_t)damp % 16) == 0 &&
                     (variant == FDTD_VARIANT_MARCH2 || fdtd_march2_preferred(g));
 
   // corners of either scatter that land in the halo layer: applied to memory by the call that owns
@@ -939,7 +971,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   // recorded on the stream around everything the call launches.
   int per_launch = env_int2("FDTD_FUSE2_WGS", 256);   // workgroups per launch (stride of the launch loop below)
   if (per_launch < 1) per_launch = 256;
-  const bool dispatch_times = fuse && ev_begin && ev_end && nzt == 1 && !many &&
+  const bool dispatch_times = fuse && !damp && ev_begin && ev_end && nzt == 1 && !many &&
                               (long)ntile * ((ex + xchunk - 1) / xchunk) <= per_launch;
   if (ev_begin && !dispatch_times) FDTD_HIP_CHECK(hipEventRecord(ev_begin, s));
 
@@ -967,14 +999,14 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     fdtd_geom g1 = *g;
     g1.x_m = g->x_m - 2 > dx_m ? g->x_m - 2 : dx_m;
     g1.x_M = g->x_M + 2 < dx_M ? g->x_M + 2 : dx_M;
-    int rc = fdtd_stencil_levels(&g1, m, cur, prev, c_lvl, v1, stream);
+    int rc = sweep(&g1, cur, prev, c_lvl, v1);
     if (rc) return rc;
     if (has_src) {
       rc = fdtd_inject_level(g, m, src, src_coords, c_lvl, time, p_src_m, p_src_M, src_stride, coord_stride,
                              x_shift, g1.x_m + x_shift, g1.x_M + x_shift, 2, gx_m, gx_M, stream);
       if (rc) return rc;
     }
-    rc = fdtd_stencil_levels(g, m, c_lvl, cur, next2, v1, stream);
+    rc = sweep(g, c_lvl, cur, next2, v1);
     if (rc) return rc;
     // back into next1: the range, and on request the extra planes the caller has no other source for
     const int back_lo = (flags & 4) ? g1.x_m : g->x_m, back_hi = (flags & 8) ? g1.x_M : g->x_M;
@@ -998,14 +1030,14 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     fdtd_geom g1 = *g;
     g1.x_m = g->x_m - 2 > dx_m ? g->x_m - 2 : dx_m;
     g1.x_M = g->x_M + 2 < dx_M ? g->x_M + 2 : dx_M;
-    int rc = fdtd_stencil_levels(&g1, m, cur, prev, next1, v1, stream);
+    int rc = sweep(&g1, cur, prev, next1, v1);
     if (rc) return rc;
     if (has_src) {
       rc = fdtd_inject_level(g, m, src, src_coords, next1, time, p_src_m, p_src_M, src_stride, coord_stride,
                              x_shift, g1.x_m + x_shift, g1.x_M + x_shift, 2, gx_m, gx_M, stream);
       if (rc) return rc;
     }
-    rc = fdtd_stencil_levels(g, m, next1, cur, next2, v1, stream);
+    rc = sweep(g, next1, cur, next2, v1);
     if (rc) return rc;
     if (ev_end) FDTD_HIP_CHECK(hipEventRecord(ev_end, s));
     if (has_src)
@@ -1016,6 +1048,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
 
   March2Args a;
   a.B = (const char *)cur; a.A = (const char *)prev; a.m = (const char *)m;
+  a.damp = (const char *)damp;
   a.C = (char *)next1; a.D = (char *)next2;
   a.sx = (long)g->nyp * g->nzp; a.sy = g->nzp;
   a.x_m = g->x_m; a.x_M = g->x_M; a.dx_m = dx_m; a.dx_M = dx_M;
@@ -1030,6 +1063,8 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   a.k.r3 = 1.0F / (g->h_y * g->h_y);
   a.k.r4 = 1.0F / (g->h_z * g->h_z);
   a.k.neg2r1 = -2.0F * a.k.r1;
+  a.k.dt = g->dt;
+  a.k.r0 = 1.0F / g->dt;
   a.src_row = has_src ? src + (long)time * src_stride : nullptr;
   a.src_row2 = has_src ? src + (long)(time + 1) * src_stride : nullptr;
   a.coords = src_coords; a.m_f = m;
@@ -1048,15 +1083,22 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       const int b = (int)base;
 #define M2_LAUNCH(NT_, ZH_, MASK_, LPR_)                                                                    \
   do {                                                                                                       \
-    if (dispatch_times)                                                                                      \
+    if (damp)                                                                                                \
+      hipLaunchKernelGGL((stencil_march2_kernel<true, ZH_, MASK_, LPR_, true>), grid, block, 0, s, a, xchunk, nyt, nzt, b); \
+    else if (dispatch_times)                                                                                 \
       hipExtLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_, LPR_>), grid, block, 0, s, ev_begin, ev_end, 0, \
                             a, xchunk, nyt, nzt, b);                                                         \
     else                                                                                                     \
       hipLaunchKernelGGL((stencil_march2_kernel<NT_, ZH_, MASK_, LPR_>), grid, block, 0, s, a, xchunk, nyt, nzt, b); \
   } while (0)
       if (zstep == 0) {
-        if (tl.mask) hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, true>), grid, block, 0, s, a, xchunk, tl.mixed, b);
-        else hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, false>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+        if (damp) {
+          if (tl.mask) hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, true, true>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+          else hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, false, true>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+        } else {
+          if (tl.mask) hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, true>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+          else hipLaunchKernelGGL((stencil_march2_mixed_kernel<true, false>), grid, block, 0, s, a, xchunk, tl.mixed, b);
+        }
       } else if (zstep == M2_ZCELLS) {
         if (tl.mask) { if (nt) M2_LAUNCH(true, 2, true, 64); else M2_LAUNCH(false, 2, true, 64); }
         else { if (nt) M2_LAUNCH(true, 2, false, 64); else M2_LAUNCH(false, 2, false, 64); }
@@ -1079,7 +1121,7 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
   }
   if (nzt > 1) {
     SeamArgs sa;
-    sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2;
+    sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2; sa.damp = damp;
     sa.sx = a.sx; sa.sy = a.sy; sa.x_m = g->x_m; sa.y_m = g->y_m; sa.y_M = g->y_M; sa.z_m = g->z_m;
     sa.k = a.k;
     // eight cuts per launch; grid.z is limited to 65535 planes
@@ -1089,14 +1131,15 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
       for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
         sa.x_m = x0;
         const int planes = g->x_M - x0 + 1 < 65535 ? g->x_M - x0 + 1 : 65535;
-        hipLaunchKernelGGL(seam_kernel, dim3((unsigned)((ey + 255) / 256), (unsigned)ncut, (unsigned)planes), dim3(256),
-                           0, s, sa);
+        const dim3 sgrid((unsigned)((ey + 255) / 256), (unsigned)ncut, (unsigned)planes);
+        if (damp) hipLaunchKernelGGL(seam_kernel<true>, sgrid, dim3(256), 0, s, sa);
+        else hipLaunchKernelGGL(seam_kernel<false>, sgrid, dim3(256), 0, s, sa);
       }
     }
   }
   if (many) {
     RepairArgs ra;
-    ra.C = next1; ra.B = cur; ra.m = m; ra.coords = src_coords; ra.D = next2;
+    ra.C = next1; ra.B = cur; ra.m = m; ra.coords = src_coords; ra.D = next2; ra.damp = damp;
     ra.sx = a.sx; ra.sy = a.sy;
     ra.x_m = g->x_m; ra.x_M = g->x_M; ra.y_m = g->y_m; ra.y_M = g->y_M; ra.z_m = g->z_m; ra.z_M = g->z_M;
     ra.cx_m = grown_lo; ra.cx_M = grown_hi; ra.x_shift = x_shift;
@@ -1104,7 +1147,8 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     ra.h_x = g->h_x; ra.h_y = g->h_y; ra.h_z = g->h_z; ra.o_x = g->o_x; ra.o_y = g->o_y; ra.o_z = g->o_z;
     ra.k = a.k;
     const long threads = (long)nsrc * 8 * 13;
-    hipLaunchKernelGGL(repair_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, ra);
+    if (damp) hipLaunchKernelGGL(repair_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, ra);
+    else hipLaunchKernelGGL(repair_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, ra);
   }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
@@ -1120,7 +1164,19 @@ extern "C" int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, con
                                   float *next1, float *next2, int time, int p_src_m, int p_src_M,
                                   int src_stride, int coord_stride, int variant, void *stream) {
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
-                             coord_stride, variant, 0, 0, 0, stream, nullptr, nullptr, nullptr, 0);
+                             coord_stride, variant, 0, 0, 0, stream, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+// The same two steps with the damping term of the forward operator (fdtd_forward.hip): damp has the padded shape of
+// m.  No reference arithmetic exists for it (parity unpinned); with damp = 0 everywhere the results are those of
+// fdtd_hip_two_steps.
+extern "C" int fdtd_hip_two_steps_damped(const struct fdtd_geom *g, const float *m, const float *damp, const float *src,
+                                         const float *src_coords, const float *cur, const float *prev, float *next1,
+                                         float *next2, int time, int p_src_m, int p_src_M, int src_stride,
+                                         int coord_stride, int variant, int flags, void *stream) {
+  if (!damp) return (int)hipErrorInvalidValue;
+  return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
+                             coord_stride, variant, flags & 0xffff, 0, 0, stream, nullptr, nullptr, nullptr, 0, damp);
 }
 
 extern "C" int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, const float *src,
@@ -1130,7 +1186,7 @@ extern "C" int fdtd_hip_two_steps_ex(const struct fdtd_geom *g, const float *m, 
                                      void *ev_begin, void *ev_end, void *stream) {
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
                              coord_stride, variant, flags & 0xffff, 0, 0, stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end,
-                             nullptr, 0);
+                             nullptr, 0, nullptr);
 }
 
 // Slab form of fdtd_hip_two_steps (see fdtd_two_steps_impl) and of fdtd_hip_one_step: local arrays
@@ -1143,7 +1199,7 @@ extern "C" int fdtd_hip_two_steps_slab(const struct fdtd_geom *g, const float *m
   if (global_nx <= 0) return (int)hipErrorInvalidValue;
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
                              coord_stride, variant, flags & 0xffff, x_shift, global_nx, stream, nullptr, nullptr, scratch,
-                             scratch_floats);
+                             scratch_floats, nullptr);
 }
 
 // Allocation-free form of fdtd_hip_two_steps_slab for callers that cannot allocate device memory
@@ -1230,7 +1286,7 @@ extern "C" int fdtd_hip_two_steps_slab_noalloc(const struct fdtd_geom *g, const 
   // the size of the range is checked where the path is chosen: only the two-sweep path needs the array
   return fdtd_two_steps_impl(g, m, src, src_coords, cur, prev, next1, next2, time, p_src_m, p_src_M, src_stride,
                              coord_stride, variant, (flags & 0xffff) | M2_FLAG_STATIC_SCRATCH, x_shift, global_nx, stream,
-                             nullptr, nullptr, ss->ptr, (long)FDTD_STATIC_SCRATCH_FLOATS);
+                             nullptr, nullptr, ss->ptr, (long)FDTD_STATIC_SCRATCH_FLOATS, nullptr);
 }
 
 extern "C" int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const float *src,

@@ -154,27 +154,6 @@ int pick_devices(int deviceid, std::vector<int> *out) {
   return 0;
 }
 
-// Do the three ring levels of the host array carry bit-identical shells (the two layers of cells around
-// the updated box)?  Then no shell has to follow the ring through the four rotating buffers.
-bool host_shells_identical(const float *u, size_t vol, const fdtd_geom &g) {
-  const long sx = (long)g.nyp * g.nzp, sy = g.nzp;
-  const int ez = g.z_M - g.z_m + 1;
-  for (int x = g.x_m - 2; x <= g.x_M + 2; ++x)
-    for (int y = g.y_m - 2; y <= g.y_M + 2; ++y) {
-      const bool whole = x < g.x_m || x > g.x_M || y < g.y_m || y > g.y_M;
-      const long row = (long)(x + FDTD_HALO) * sx + (long)(y + FDTD_HALO) * sy + FDTD_HALO + g.z_m - 2;
-      for (int l = 1; l < 3; ++l) {
-        const float *a = u + row, *b = u + (size_t)l * vol + row;
-        if (whole) {
-          if (memcmp(a, b, (size_t)(ez + 4) * sizeof(float))) return false;
-        } else if (memcmp(a, b, 2 * sizeof(float)) || memcmp(a + ez + 2, b + ez + 2, 2 * sizeof(float))) {
-          return false;
-        }
-      }
-    }
-  return true;
-}
-
 int g_multigpu_last_slabs = 0;
 
 }  // namespace
@@ -462,22 +441,9 @@ struct fdtd_multigpu {
       fdtd_geom g = v.g;
       if (v.left >= 0) g.x_m = -2;
       if (v.right >= 0) g.x_M = v.nx + 1;
-      int pos[3] = {cur, prev, third};
-      int free_pos = spare;
-      for (int it = 0; it < 8; ++it) {
-        int mover = -1;
-        for (int r = 0; r < 3; ++r)
-          if (pos[r] != tgt_of[r] && tgt_of[r] == free_pos) mover = r;
-        if (mover < 0)
-          for (int r = 0; r < 3; ++r)
-            if (pos[r] != tgt_of[r]) mover = r;
-        if (mover < 0) break;
-        const int rc = fdtd_hip_copy_shell(&g, v.lv[free_pos], v.lv[pos[mover]], 1, v.edge);
-        if (rc) return rc;
-        const int old = pos[mover];
-        pos[mover] = free_pos;
-        free_pos = old;
-      }
+      const int pos[3] = {cur, prev, third};
+      const int rc = fdtd_ring_settle(&g, v.lv, pos, spare, tgt_of, v.edge);
+      if (rc) return rc;
       FDTD_HIP_CHECK(hipStreamSynchronize(v.edge));
     }
     cur = tgt_of[0]; prev = tgt_of[1]; third = tgt_of[2]; spare = 3;
@@ -532,15 +498,7 @@ int set_sources_impl(fdtd_multigpu *h, const float *src, int src_steps, int src_
   h->prepared = false;
   if (!has_src) return 0;
   if (p_src_m < 0 || p_src_M >= src_stride || p_src_M >= coord_rows || coord_stride < 3) return (int)hipErrorInvalidValue;
-  const fdtd_geom &G = h->G;
-  // can a source corner reach the halo layer?  (positions as openacc.cpp:185-187 computes them)
-  for (int p = p_src_m; p <= p_src_M && h->sources_inside; ++p) {
-    const int posx = (int)floorf((-G.o_x + coords[(size_t)p * coord_stride + 0]) / G.h_x);
-    const int posy = (int)floorf((-G.o_y + coords[(size_t)p * coord_stride + 1]) / G.h_y);
-    const int posz = (int)floorf((-G.o_z + coords[(size_t)p * coord_stride + 2]) / G.h_z);
-    h->sources_inside = !(posx < G.x_m || posx + 1 > G.x_M || posy < G.y_m || posy + 1 > G.y_M || posz < G.z_m ||
-                          posz + 1 > G.z_M);
-  }
+  h->sources_inside = fdtd_host_sources_inside(coords, coord_stride, p_src_m, p_src_M, h->G);
   const size_t n_src = (size_t)src_steps * src_stride, n_coords = (size_t)coord_rows * coord_stride;
   for (Dev &v : h->d) {
     FDTD_HIP_CHECK(hipSetDevice(v.id));
@@ -699,7 +657,7 @@ extern "C" int fdtd_hip_multigpu_upload(fdtd_multigpu *h, const float *u, const 
   if (!h || !u) return (int)hipErrorInvalidValue;
   DeviceGuard guard;
   const size_t plane = h->plane, vol = (size_t)h->G.nxp * plane;
-  h->shells_identical = host_shells_identical(u, vol, h->G);
+  h->shells_identical = fdtd_host_shells_identical(u, vol, h->G);
   auto up = [&](Dev &v) -> int {
     FDTD_HIP_CHECK(hipSetDevice(v.id));
     const size_t lvol = (size_t)(v.nx + 2 * FDTD_HALO) * plane;

@@ -156,9 +156,10 @@ int fdtd_hip_get_space_order(void);
  * so there is no reference arithmetic for this entry: parity unpinned.  With damp = 0 the update is the
  * expression of openacc.cpp:159-164; the interpolation is the transpose of the scatter of
  * openacc.cpp:185-196.  Argument conventions of the operator ABI; p_rec_M < p_rec_m: no receivers.
- * Every space order (fdtd_hip_set_space_order).  Boxes of 12 M cells and more take the marching sweep of the
- * space orders with the damping field as one more streamed operand, smaller ones a one-cell-per-thread
- * kernel: same bits. */
+ * Every space order (fdtd_hip_set_space_order).  At order 4, boxes the two-step sweep is made for (16 M cells
+ * and more, rows of whole float4s) run two damped steps per sweep (fdtd_hip_two_steps_damped: 12 instead of 20
+ * bytes per cell update); otherwise boxes of 12 M cells and more take the marching sweep of the space orders with
+ * the damping field as one more streamed operand, smaller ones a one-cell-per-thread kernel: same bits. */
 int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
                        struct dataobj *rec_coords_vec, struct dataobj *src_vec,
                        struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,
@@ -168,6 +169,9 @@ int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct d
                        const int p_rec_m, const int p_src_M, const int p_src_m, const int time_M,
                        const int time_m, const int deviceid, const int devicerm,
                        struct profiler *timers);
+
+/* 1 when the last Kernel_HIP_Forward call ran two steps per sweep, 0 when it ran one sweep per step. */
+int fdtd_hip_forward_last_call_fused(void);
 
 /* Optional hook the reference driver looks up as a weak symbol and calls once per
  * benchmark sweep (main.cpp:84,266-276).  The call records the values and returns.
@@ -275,6 +279,16 @@ int fdtd_hip_two_steps(const struct fdtd_geom *g, const float *m, const float *s
                        const float *src_coords, const float *cur, const float *prev,
                        float *next1, float *next2, int time, int p_src_m, int p_src_M,
                        int src_stride, int coord_stride, int variant, void *stream);
+
+/* fdtd_hip_two_steps_ex with the damping term of Kernel_HIP_Forward: damp is a device array of the padded
+ * shape of m; u+ = dt^2 (lap - (-2 r1 u + r1 u-) m + r0 damp u) / (m + dt damp).  No reference arithmetic
+ * (parity unpinned); where damp is 0 the values are those of fdtd_hip_two_steps.  Same shapes, same fall-back
+ * to two single (damped) sweeps, same source handling; flags as for fdtd_hip_two_steps_ex. */
+int fdtd_hip_two_steps_damped(const struct fdtd_geom *g, const float *m, const float *damp,
+                              const float *src, const float *src_coords, const float *cur,
+                              const float *prev, float *next1, float *next2, int time, int p_src_m,
+                              int p_src_M, int src_stride, int coord_stride, int variant, int flags,
+                              void *stream);
 
 /* Would fdtd_hip_two_steps take the fused sweep for this box with nsrc sources (levels assumed
  * 16-byte aligned)?  1 or 0; variant as for fdtd_hip_two_steps. */

@@ -100,7 +100,47 @@ def test_forward_operator_full_size_default_path(pkg, hiplib, n):
     assert rc == 0
     rc, prof = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h)
     assert rc == 0 and prof.section0 > 0
+    assert hiplib.fdtd_hip_forward_last_call_fused() == 1      # two damped steps per sweep
     assert ob.bits_equal(u, u_ref) and ob.bits_equal(rec, rec_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nsrc,nt", [((34, 16, 512), 2, 11), ((36, 32, 256), 3, 10), ((34, 16, 1024), 3, 9),
+                                       ((40, 24, 384), 2, 8), ((33, 20, 640), 1, 12), ((34, 40, 128), 12, 7),
+                                       ((36, 13, 516), 2, 9)])
+def test_forward_operator_two_steps_per_sweep(pkg, hiplib, monkeypatch, n, nsrc, nt):
+    """The damped two-step sweep on small boxes (switches let it take them): whole-row tiles, two tiles per workgroup,
+    rows cut into z-tiles (seam pass), mixed and masked tilings, more than 8 sources (repair pass), odd step counts,
+    different halos per ring level, a source in the outermost cell, receivers in the halo layer."""
+    monkeypatch.setenv("FDTD_FUSE2_MIN_CELLS", "0")
+    monkeypatch.setenv("FDTD_FUSE2_MIN_FILL", "0")
+    u, m, src, coords, rec, rcoords, h = random_case(n, nt, nsrc, 5, 60 + n[2])
+    coords[0] = ((n[0] - 1) * h[0] + 0.4 * h[0], 3.3 * h[1], 9.7 * h[2])     # outermost cell: corners in the halo layer
+    damp = sponge(m.shape, 5, 40.0)
+    u_ref, rec_ref = u.copy(), rec.copy()
+    rc, _ = pkg.run_forward(ob.oracle().Oracle_Kernel_Forward, damp, m, rec_ref, rcoords, src, coords, u_ref, h=h)
+    assert rc == 0
+    before = hiplib.fdtd_hip_fused_launch_count()
+    rc, prof = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h)
+    assert rc == 0 and prof.section0 > 0
+    assert hiplib.fdtd_hip_forward_last_call_fused() == 1 and hiplib.fdtd_hip_fused_launch_count() > before
+    assert ob.bits_equal(u, u_ref)
+    assert ob.bits_equal(rec, rec_ref) and np.isfinite(rec).all()
+
+
+@pytest.mark.gpu
+def test_two_step_forward_without_sponge_is_the_reference_update(pkg, hiplib, monkeypatch):
+    """damp = 0 through the damped two-step sweep gives the values of Kernel_CUDA_Optimized (fixture-checked)."""
+    monkeypatch.setenv("FDTD_FUSE2_MIN_CELLS", "0")
+    n, nt = (40, 16, 512), 13
+    u, m, src, coords, rec, rcoords, h = random_case(n, nt, 3, 3, 8)
+    damp = np.zeros_like(m)
+    u_plain = u.copy()
+    rc, _ = pkg.run_operator(hiplib.Kernel_CUDA_Optimized, m, src, coords, u_plain, h=h)
+    assert rc == 0
+    rc, _ = pkg.run_forward(hiplib.Kernel_HIP_Forward, damp, m, rec, rcoords, src, coords, u, h=h)
+    assert rc == 0 and hiplib.fdtd_hip_forward_last_call_fused() == 1
+    assert np.array_equal(u, u_plain)          # same values (a negative zero may come out positive)
 
 
 def test_generic_restatement_at_order_4_is_the_order_4_restatement(pkg):
