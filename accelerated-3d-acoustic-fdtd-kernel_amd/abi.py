@@ -94,6 +94,14 @@ def lib():
         fn.restype = C.c_int
     L.Kernel_HIP_Forward.argtypes = FORWARD_ARGTYPES
     L.Kernel_HIP_Forward.restype = C.c_int
+    L.Kernel_HIP_ForwardOrder.argtypes = FORWARD_ARGTYPES + [C.c_int]
+    L.Kernel_HIP_ForwardOrder.restype = C.c_int
+    L.Kernel_HIP_SpaceOrder.argtypes = OPERATOR_ARGTYPES + [C.c_int]
+    L.Kernel_HIP_SpaceOrder.restype = C.c_int
+    L.fdtd_hip_time_loop_order.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.POINTER(Profiler)]
+    L.fdtd_hip_time_loop_order.restype = C.c_int
     L.fdtd_hip_stencil_step_damped.argtypes = [C.POINTER(Geom), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                C.c_int, C.c_void_p]
     L.fdtd_hip_stencil_step_damped.restype = C.c_int

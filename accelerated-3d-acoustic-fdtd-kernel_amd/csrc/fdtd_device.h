@@ -74,6 +74,15 @@ int fdtd_stencil_levels_damped(const struct fdtd_geom *g, const float *m, const 
                                const float *u1, float *u2, int order, void *stream);
 
 extern "C" int fdtd_hip_get_space_order(void);
+// Space order of the call in progress on this thread: set (returns the value before), 0 = none, in which case
+// fdtd_hip_get_space_order reports the process-wide setting.  OrderScope sets it for a scope.
+int fdtd_space_order_for_this_call(int order);
+bool fdtd_space_order_supported(int order);
+struct OrderScope {
+  int before;
+  explicit OrderScope(int order) : before(fdtd_space_order_for_this_call(order)) {}
+  ~OrderScope() { fdtd_space_order_for_this_call(before); }
+};
 
 // Sweep and scatter in one launch for small grids (fdtd_kernels.hip).
 struct FdtdSmallSource {

@@ -284,3 +284,20 @@ extern "C" int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_ve
 
 // 1 when the last Kernel_HIP_Forward call ran two steps per sweep, 0 when it ran one sweep per step.
 extern "C" int fdtd_hip_forward_last_call_fused(void) { return g_forward_last_fused; }
+
+// Kernel_HIP_Forward at a space order given with the call (this call, this thread; the process-wide setting is
+// neither read nor changed).
+extern "C" int Kernel_HIP_ForwardOrder(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
+                                       struct dataobj *rec_coords_vec, struct dataobj *src_vec,
+                                       struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,
+                                       const int x_m, const int y_M, const int y_m, const int z_M, const int z_m,
+                                       const float dt, const float h_x, const float h_y, const float h_z, const float o_x,
+                                       const float o_y, const float o_z, const int p_rec_M, const int p_rec_m,
+                                       const int p_src_M, const int p_src_m, const int time_M, const int time_m,
+                                       const int deviceid, const int devicerm, struct profiler *timers, int space_order) {
+  if (!fdtd_space_order_supported(space_order)) return (int)hipErrorInvalidValue;
+  OrderScope scope(space_order);
+  return Kernel_HIP_Forward(damp_vec, m_vec, rec_vec, rec_coords_vec, src_vec, src_coords_vec, u_vec, x_M, x_m, y_M, y_m,
+                            z_M, z_m, dt, h_x, h_y, h_z, o_x, o_y, o_z, p_rec_M, p_rec_m, p_src_M, p_src_m, time_M, time_m,
+                            deviceid, devicerm, timers);
+}

@@ -464,6 +464,16 @@ extern "C" int fdtd_hip_time_loop(const struct fdtd_geom *g, const float *m, con
                         time_m, time_M, variant, stream, timers);
 }
 
+extern "C" int fdtd_hip_time_loop_order(const struct fdtd_geom *g, const float *m, const float *src,
+                                        const float *src_coords, float *u, int p_src_m, int p_src_M,
+                                        int src_stride, int coord_stride, int time_m, int time_M,
+                                        int variant, int space_order, void *stream, struct profiler *timers) {
+  if (!fdtd_space_order_supported(space_order)) return (int)hipErrorInvalidValue;
+  OrderScope scope(space_order);
+  return time_loop_impl(false, g, m, src, src_coords, u, p_src_m, p_src_M, src_stride, coord_stride,
+                        time_m, time_M, variant, stream, timers);
+}
+
 namespace {
 
 struct DeviceBuffers {
@@ -786,6 +796,15 @@ extern "C" int Kernel_CUDA_Optimized(FDTD_OPERATOR_ARGS) {
   int variant = optimized_variant();
   if (variant == FDTD_VARIANT_AUTO && g_cfg_t_fuse >= 2) variant = FDTD_VARIANT_MARCH2;
   return FDTD_FORWARD(variant);
+}
+
+// Kernel_CUDA_Optimized at a space order given with the call (arrays padded by that many cells): the order
+// holds for this call on this thread only and neither reads nor changes the process-wide setting.
+extern "C" int Kernel_HIP_SpaceOrder(FDTD_OPERATOR_ARGS, int space_order) {
+  if (!fdtd_space_order_supported(space_order)) return (int)hipErrorInvalidValue;
+  OrderScope scope(space_order);
+  return Kernel_CUDA_Optimized(m_vec, src_vec, src_coords_vec, u_vec, x_M, x_m, y_M, y_m, z_M, z_m, dt, h_x, h_y, h_z, o_x,
+                               o_y, o_z, p_src_M, p_src_m, time_M, time_m, deviceid, devicerm, timers);
 }
 
 extern "C" int Kernel_HIP_FP16Storage(FDTD_OPERATOR_ARGS) {

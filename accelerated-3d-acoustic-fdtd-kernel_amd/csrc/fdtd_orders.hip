@@ -307,6 +307,9 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
 }
 
 int g_space_order = 0;   // 0: not set yet (FDTD_STENCIL_ORDER, else 4)
+// The order of the call in progress on this thread (the *_order / Kernel_HIP_SpaceOrder entry points): it
+// takes precedence over the process-wide setting, so those entry points neither read nor change it.
+thread_local int t_call_order = 0;
 
 bool order_supported(int order) { return order >= 4 && order <= 2 * MAX_R && order % 2 == 0; }
 
@@ -390,7 +393,15 @@ extern "C" int fdtd_hip_set_space_order(int order) {
   return 0;
 }
 
+int fdtd_space_order_for_this_call(int order) {
+  const int before = t_call_order;
+  t_call_order = order;
+  return before;
+}
+bool fdtd_space_order_supported(int order) { return order_supported(order); }
+
 extern "C" int fdtd_hip_get_space_order(void) {
+  if (t_call_order) return t_call_order;
   if (g_space_order == 0) {
     const char *e = getenv("FDTD_STENCIL_ORDER");
     const int v = e ? atoi(e) : 4;

@@ -149,6 +149,12 @@ void fdtd_hip_last_call_phases(double out_ms[4]);
  * (non-zero return) and leaves the order as it was. */
 int fdtd_hip_set_space_order(int order);
 int fdtd_hip_get_space_order(void);
+/* The same with the order given per call, for programs that run operators of several orders, or from several
+ * threads: Kernel_HIP_SpaceOrder is Kernel_CUDA_Optimized on arrays padded by space_order cells per side,
+ * Kernel_HIP_ForwardOrder (declared with Kernel_HIP_Forward) and fdtd_hip_time_loop_order (with
+ * fdtd_hip_time_loop) likewise.  The order holds for that call on the calling thread only; the process-wide
+ * setting is neither read nor changed.  An unsupported order is refused with hipErrorInvalidValue. */
+int Kernel_HIP_SpaceOrder(FDTD_OPERATOR_ARGS, int space_order);
 /* The forward operator of a Devito-style acoustic propagator around the same path: the update with an
  * absorbing sponge (damp, padded shape of m), the source scatter, and receivers that sample the wavefield
  * (rec[time][p] at rec_coords[p][3], trilinear, the level the step starts from).  The reference has
@@ -170,6 +176,15 @@ int Kernel_HIP_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struct d
                        const int time_m, const int deviceid, const int devicerm,
                        struct profiler *timers);
 
+int Kernel_HIP_ForwardOrder(struct dataobj *damp_vec, struct dataobj *m_vec, struct dataobj *rec_vec,
+                            struct dataobj *rec_coords_vec, struct dataobj *src_vec,
+                            struct dataobj *src_coords_vec, struct dataobj *u_vec, const int x_M,
+                            const int x_m, const int y_M, const int y_m, const int z_M, const int z_m,
+                            const float dt, const float h_x, const float h_y, const float h_z,
+                            const float o_x, const float o_y, const float o_z, const int p_rec_M,
+                            const int p_rec_m, const int p_src_M, const int p_src_m, const int time_M,
+                            const int time_m, const int deviceid, const int devicerm,
+                            struct profiler *timers, int space_order);
 /* 1 when the last Kernel_HIP_Forward call ran two steps per sweep, 0 when it ran one sweep per step. */
 int fdtd_hip_forward_last_call_fused(void);
 
@@ -453,6 +468,11 @@ int fdtd_hip_time_loop(const struct fdtd_geom *g, const float *m, const float *s
                        const float *src_coords, float *u, int p_src_m, int p_src_M,
                        int src_stride, int coord_stride, int time_m, int time_M,
                        int variant, void *stream, struct profiler *timers);
+
+int fdtd_hip_time_loop_order(const struct fdtd_geom *g, const float *m, const float *src,
+                             const float *src_coords, float *u, int p_src_m, int p_src_M,
+                             int src_stride, int coord_stride, int time_m, int time_M,
+                             int variant, int space_order, void *stream, struct profiler *timers);
 
 /* fp16-storage counterparts (u is __half[3][nxp][nyp][nzp]; m, src stay fp32). */
 int fdtd_hip_stencil_step_h16(const struct fdtd_geom *g, const float *m, void *u_h16,

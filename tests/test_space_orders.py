@@ -128,6 +128,55 @@ def test_operators_at_space_order(pkg, hiplib, order):
     assert hiplib.fdtd_hip_get_space_order() == 4
 
 
+@pytest.mark.gpu
+def test_order_given_per_call_is_independent_of_the_process_setting(pkg, hiplib):
+    """Kernel_HIP_SpaceOrder / Kernel_HIP_ForwardOrder take the order with the call: two threads run orders 8 and 12
+    at the same time while the process-wide order stays 6, and each gets the generic oracle's bits."""
+    import threading
+    from test_forward_operator import random_case, sponge
+    assert hiplib.fdtd_hip_set_space_order(6) == 0
+    results = {}
+
+    def work(order):
+        n, nt = (20, 36, 44), 9
+        u0, m, src, coords, kw = padded_case(order, n, nt, 2, 70 + order, None, True)
+        u_ref = u0.copy()
+        ob.run_oracle_order(order, m, src, coords, u_ref, **kw)
+        ok = True
+        for _ in range(4):
+            u = u0.copy()
+
+            def call(*args):
+                return hiplib.Kernel_HIP_SpaceOrder(*args, order)
+            rc, _ = pkg.run_operator(call, m, src, coords, u, **kw)
+            ok = ok and rc == 0 and ob.bits_equal(u, u_ref)
+        # the forward operator the same way
+        u, mm, s2, c2, rec, rcoords, h = random_case(n, nt, 2, 4, 90 + order, halo=order)
+        damp = sponge(mm.shape, 6, 40.0, halo=order)
+        b = (0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1)
+        u_r, rec_r = u.copy(), rec.copy()
+        assert pkg.run_forward(ob.forward_oracle_order(order), damp, mm, rec_r, rcoords, s2, c2, u_r, h=h, bounds=b)[0] == 0
+
+        def fwd(*args):
+            return hiplib.Kernel_HIP_ForwardOrder(*args, order)
+        rc, _ = pkg.run_forward(fwd, damp, mm, rec, rcoords, s2, c2, u, h=h, bounds=b)
+        results[order] = ok and rc == 0 and ob.bits_equal(u, u_r) and ob.bits_equal(rec, rec_r)
+
+    try:
+        threads = [threading.Thread(target=work, args=(o,)) for o in (8, 12)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert results == {8: True, 12: True}
+        assert hiplib.fdtd_hip_get_space_order() == 6
+        u0, m, _, _, kw = padded_case(4, (16, 16, 16), 3, 0, 1)
+        rc, _ = pkg.run_operator(lambda *a: hiplib.Kernel_HIP_SpaceOrder(*a, 7), m, None, None, u0, **kw)   # no such order
+        assert rc == 1
+    finally:
+        assert hiplib.fdtd_hip_set_space_order(4) == 0
+
+
 def _one_sweep(pkg, hiplib, order, n, bounds, seed, monkeypatch=None):
     """One sweep of fdtd_hip_stencil_step_order against the oracle's on a random field; returns the two fields."""
     import torch
