@@ -125,6 +125,9 @@ def lib():
                                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_void_p]
     L.fdtd_hip_source_inject_order.restype = C.c_int
+    L.fdtd_hip_source_inject_slab_order.argtypes = L.fdtd_hip_source_inject_order.argtypes[:-2] + [
+        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.fdtd_hip_source_inject_slab_order.restype = C.c_int
     L.fdtd_hip_multigpu_last_slab_count.argtypes = []
     L.fdtd_hip_multigpu_last_slab_count.restype = C.c_int
     L.fdtd_hip_multigpu_create.argtypes = [C.POINTER(Geom), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]

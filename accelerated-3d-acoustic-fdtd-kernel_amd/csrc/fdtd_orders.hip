@@ -506,3 +506,16 @@ extern "C" int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const flo
   return fdtd_inject_level_halo(g, m, src, src_coords, u + (long)t2 * vol, time, p_src_m, p_src_M, src_stride,
                                 coord_stride, 0, g->x_m - 1, g->x_M + 1, 0, 0, 0, order, stream);
 }
+
+// Slab form of the scatter at any space order (arrays padded by `order` cells hold global planes x_shift-order ..;
+// a corner is applied iff its global x index lies in [x_lo, x_hi]): fdtd_hip_source_inject_slab for the wider padding.
+extern "C" int fdtd_hip_source_inject_slab_order(const struct fdtd_geom *g, const float *m, const float *src,
+                                                 const float *src_coords, float *u, int t2, int time, int p_src_m,
+                                                 int p_src_M, int src_stride, int coord_stride, int x_shift, int x_lo,
+                                                 int x_hi, int order, void *stream) {
+  if (p_src_M < p_src_m) return 0;
+  if (!g || !u || t2 < 0 || t2 > 2 || !order_supported(order)) return (int)hipErrorInvalidValue;
+  const long vol = (long)g->nxp * g->nyp * g->nzp;
+  return fdtd_inject_level_halo(g, m, src, src_coords, u + (long)t2 * vol, time, p_src_m, p_src_M, src_stride,
+                                coord_stride, x_shift, x_lo, x_hi, 0, 0, 0, order, stream);
+}

@@ -38,14 +38,17 @@ GHOST = 2  # radius of the stencil = planes exchanged per side
 class SlabLayout:
     """Index arithmetic of the x-slab decomposition of NX interior planes over `world` ranks."""
 
-    def __init__(self, NX, world):
+    def __init__(self, NX, world, order=2 * GHOST):
+        """`order`: space order of the stencil; the arrays are padded by `order` cells per side (main.cpp:32) and
+        order / 2 planes are exchanged per side and step."""
         if world < 1 or NX < world:
             raise ValueError("need at least one plane per rank")
         base, rem = divmod(NX, world)
         self.NX, self.world = NX, world
+        self.halo, self.ghost = order, order // 2
         self.counts = [base + (1 if r < rem else 0) for r in range(world)]
         self.offsets = [sum(self.counts[:r]) for r in range(world)]
-        if world > 1 and min(self.counts) < GHOST:
+        if world > 1 and min(self.counts) < self.ghost:
             raise ValueError("slabs thinner than the stencil radius are not supported")
 
     def nx_loc(self, rank):
@@ -63,16 +66,16 @@ class SlabLayout:
     def cut(self, global_padded, rank, axis):
         """Local padded view [x_off, x_off + nx_loc + 8) of a globally padded array along `axis`."""
         sl = [slice(None)] * global_padded.ndim
-        sl[axis] = slice(self.offsets[rank], self.offsets[rank] + self.counts[rank] + 2 * HALO)
+        sl[axis] = slice(self.offsets[rank], self.offsets[rank] + self.counts[rank] + 2 * self.halo)
         return global_padded[tuple(sl)]
 
     def paste_owned(self, global_padded, local_padded, rank, axis):
         """Write a rank's owned planes (plus the physical halo on the first/last rank) back."""
-        lo, hi = HALO, HALO + self.counts[rank]
+        lo, hi = self.halo, self.halo + self.counts[rank]
         if rank == 0:
             lo = 0
         if rank == self.world - 1:
-            hi = self.counts[rank] + 2 * HALO
+            hi = self.counts[rank] + 2 * self.halo
         src = [slice(None)] * local_padded.ndim
         dst = [slice(None)] * global_padded.ndim
         src[axis] = slice(lo, hi)
@@ -88,12 +91,16 @@ def source_floor_planes(coords, o_x, h_x):
 
 
 class SlabPropagator:
-    """Time stepping of one slab.  `u` is the local [3][nx_loc+8][nyp][nzp] tensor, `m` the local
-    [nx_loc+8][nyp][nzp] tensor (both torch tensors on the stepper's device, ghosts filled)."""
+    """Time stepping of one slab, one step per exchange.  `u` is the local [3][nx_loc+2H][nyp][nzp] tensor, `m`
+    the local [nx_loc+2H][nyp][nzp] tensor (both torch tensors on the stepper's device, ghosts filled), H = the
+    layout's padding = the space order (4 by default; 6 .. 12: the sweeps of the higher space orders, order / 2
+    ghost planes per side).  `damp` (shape of m, or None): the damped update of the forward operator; it has no
+    reference arithmetic, like the higher orders (parity unpinned)."""
 
-    def __init__(self, layout, rank, u, m, src, coords, *, dt, h, o, stepper, comm):
+    def __init__(self, layout, rank, u, m, src, coords, *, dt, h, o, stepper, comm, damp=None):
         self.layout, self.rank = layout, rank
-        self.u, self.m = u, m
+        self.u, self.m, self.damp = u, m, damp
+        self.halo, self.ghost, self.order = layout.halo, layout.ghost, layout.halo
         self.nx = layout.nx_loc(rank)
         self.x_off = layout.x_off(rank)
         self.dt, self.h, self.o = dt, h, o
@@ -104,12 +111,13 @@ class SlabPropagator:
         # regions of owned scatter targets: left boundary, right boundary, interior (global x)
         nx, xo = self.nx, self.x_off
         exchanging = layout.world > 1 or getattr(comm, "has_neighbours", False)
-        self.overlap = exchanging and nx >= 2 * GHOST + 1
+        G = self.ghost
+        self.overlap = exchanging and nx >= 2 * G + 1
         if self.overlap:
             self.regions = {
-                "left": (lo, xo + GHOST - 1),
-                "right": (xo + nx - GHOST, hi),
-                "interior": (xo + GHOST, xo + nx - GHOST - 1),
+                "left": (lo, xo + G - 1),
+                "right": (xo + nx - G, hi),
+                "interior": (xo + G, xo + nx - G - 1),
             }
         else:
             self.regions = {"all": (lo, hi)}
@@ -125,16 +133,16 @@ class SlabPropagator:
     # ---- one time step (ring indices as openacc.cpp:148) ----
     def step(self, time):
         t0, t1, t2 = time % 3, (time + 2) % 3, (time + 1) % 3
-        st, nx = self.stepper, self.nx
+        st, nx, G = self.stepper, self.nx, self.ghost
         st.begin_step()
         if self.overlap:
             # the long chain is issued first so that it never queues behind the short one
-            st.stencil(GHOST, nx - GHOST - 1, t0, t1, t2, boundary=False)
+            st.stencil(G, nx - G - 1, t0, t1, t2, boundary=False)
             if self.active["interior"]:
                 st.inject(self.regions["interior"], t2, time, boundary=False)
             st.interior_done()
-            st.stencil(0, GHOST - 1, t0, t1, t2, boundary=True)
-            st.stencil(nx - GHOST, nx - 1, t0, t1, t2, boundary=True)
+            st.stencil(0, G - 1, t0, t1, t2, boundary=True)
+            st.stencil(nx - G, nx - 1, t0, t1, t2, boundary=True)
             for k in ("left", "right"):
                 if self.active[k]:
                     st.inject(self.regions[k], t2, time, boundary=True)
@@ -159,22 +167,22 @@ class SlabPropagator:
 
     # planes of level `lvl` sent to / received from the neighbours (contiguous tensor views)
     def send_left(self, lvl):
-        return self.u[lvl, HALO:HALO + GHOST]
+        return self.u[lvl, self.halo:self.halo + self.ghost]
 
     def send_right(self, lvl):
-        return self.u[lvl, HALO + self.nx - GHOST:HALO + self.nx]
+        return self.u[lvl, self.halo + self.nx - self.ghost:self.halo + self.nx]
 
     def recv_left(self, lvl):
-        return self.u[lvl, HALO - GHOST:HALO]
+        return self.u[lvl, self.halo - self.ghost:self.halo]
 
     def recv_right(self, lvl):
-        return self.u[lvl, HALO + self.nx:HALO + self.nx + GHOST]
+        return self.u[lvl, self.halo + self.nx:self.halo + self.nx + self.ghost]
 
     # ---- benchmark helpers ----
     def interior_cells(self):
         nyp, nzp = self.u.shape[2], self.u.shape[3]
-        planes = self.nx - 2 * GHOST if self.overlap else self.nx
-        return float(planes) * (nyp - 2 * HALO) * (nzp - 2 * HALO)
+        planes = self.nx - 2 * self.ghost if self.overlap else self.nx
+        return float(planes) * (nyp - 2 * self.halo) * (nzp - 2 * self.halo)
 
     def mean_interior_kernel_ms(self):
         return self.stepper.mean_interior_kernel_ms()
@@ -406,6 +414,7 @@ class HipStepper:
         # stay there (its result is what the sweep after needs).
         self.hold_interior = False
         self.time_interior = time_interior
+        self.order, self.damp_ptr = 2 * GHOST, None
         self.timing = []
         self._launches = 0
         self._geoms = {}
@@ -413,9 +422,12 @@ class HipStepper:
     def bind(self, prop):
         self.p = prop
         nxp, nyp, nzp = prop.u.shape[1:]
-        self.geom = abi.Geom(nxp, nyp, nzp, 0, prop.nx - 1, 0, nyp - 2 * HALO - 1, 0, nzp - 2 * HALO - 1,
+        H = prop.halo
+        self.geom = abi.Geom(nxp, nyp, nzp, 0, prop.nx - 1, 0, nyp - 2 * H - 1, 0, nzp - 2 * H - 1,
                              prop.dt, prop.h[0], prop.h[1], prop.h[2], prop.o[0], prop.o[1], prop.o[2])
         self.u_ptr, self.m_ptr = prop.u.data_ptr(), prop.m.data_ptr()
+        self.order = prop.order
+        self.damp_ptr = None if prop.damp is None else prop.damp.data_ptr()
         self.src_ptr = prop.src.data_ptr() if prop.nsrc else None
         self.coords_ptr = prop.coords.data_ptr() if prop.nsrc else None
         if prop.overlap:
@@ -457,21 +469,34 @@ class HipStepper:
         if timed:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        rc = self.lib.fdtd_hip_stencil_step(C.byref(g), self.m_ptr, self.u_ptr, t0, t1, t2, self.variant,
-                                            self._sh[boundary])
+        if self.damp_ptr is not None:      # the damped update (every space order)
+            rc = self.lib.fdtd_hip_stencil_step_damped_order(C.byref(g), self.m_ptr, self.damp_ptr, self.u_ptr, t0, t1, t2,
+                                                             self.order, self._sh[boundary])
+        elif self.order != 2 * GHOST:      # space orders 6 .. 12
+            rc = self.lib.fdtd_hip_stencil_step_order(C.byref(g), self.m_ptr, self.u_ptr, t0, t1, t2, self.order,
+                                                      self._sh[boundary])
+        else:
+            rc = self.lib.fdtd_hip_stencil_step(C.byref(g), self.m_ptr, self.u_ptr, t0, t1, t2, self.variant,
+                                                self._sh[boundary])
         if rc:
-            raise RuntimeError(f"fdtd_hip_stencil_step failed with hipError {rc}")
+            raise RuntimeError(f"the stencil sweep failed with hipError {rc}")
         if timed:
             e1.record(stream)
             self.timing.append((e0, e1))
 
     def inject(self, region, t2, time, boundary):
         p = self.p
-        rc = self.lib.fdtd_hip_source_inject_slab(
-            C.byref(self.geom), self.m_ptr, self.src_ptr, self.coords_ptr, self.u_ptr, t2, time,
-            0, p.nsrc - 1, p.src.shape[1], p.coords.shape[1], p.x_off, region[0], region[1], self._sh[boundary])
+        if self.order != 2 * GHOST:
+            rc = self.lib.fdtd_hip_source_inject_slab_order(
+                C.byref(self.geom), self.m_ptr, self.src_ptr, self.coords_ptr, self.u_ptr, t2, time,
+                0, p.nsrc - 1, p.src.shape[1], p.coords.shape[1], p.x_off, region[0], region[1], self.order,
+                self._sh[boundary])
+        else:
+            rc = self.lib.fdtd_hip_source_inject_slab(
+                C.byref(self.geom), self.m_ptr, self.src_ptr, self.coords_ptr, self.u_ptr, t2, time,
+                0, p.nsrc - 1, p.src.shape[1], p.coords.shape[1], p.x_off, region[0], region[1], self._sh[boundary])
         if rc:
-            raise RuntimeError(f"fdtd_hip_source_inject_slab failed with hipError {rc}")
+            raise RuntimeError(f"the slab scatter failed with hipError {rc}")
 
     # ---- two steps per exchange (SlabPairPropagator) ----
     def pairs_can_overlap(self, prop):

@@ -229,6 +229,13 @@ int fdtd_hip_source_inject_order(const struct fdtd_geom *g, const float *m, cons
                                  const float *src_coords, float *u, int t2, int time, int p_src_m,
                                  int p_src_M, int src_stride, int coord_stride, int order, void *stream);
 
+/* fdtd_hip_source_inject_slab (below) on arrays padded by `order` cells per side: the scatter of one slab of
+ * a domain cut along x, at any space order. */
+int fdtd_hip_source_inject_slab_order(const struct fdtd_geom *g, const float *m, const float *src,
+                                      const float *src_coords, float *u, int t2, int time, int p_src_m,
+                                      int p_src_M, int src_stride, int coord_stride, int x_shift,
+                                      int x_lo, int x_hi, int order, void *stream);
+
 /* The two device kernels Kernel_HIP_Forward adds to the path, on device arrays: one damped sweep, and
  * the receiver interpolation of level t of u into rec[time][p_rec_m..p_rec_M].  The _order forms take
  * the space order (arrays padded by that many cells); the plain forms are order 4. */

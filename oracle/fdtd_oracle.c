@@ -312,8 +312,12 @@ static void oracle_section1_order(int H, const float *restrict m, const float *r
                                   long nzp, int x_m, int x_M, int y_m, int y_M, int z_m, int z_M,
                                   float h_x, float h_y, float h_z, float o_x, float o_y, float o_z,
                                   int p_src_m, int p_src_M, int time, long src_stride,
-                                  long coord_stride) {
+                                  long coord_stride, int x_shift, int x_lo, int x_hi) {
+  /* x_shift / x_lo / x_hi: the slab form of oracle_section1 (arrays hold global planes x_shift-H ..,
+   * a corner is applied iff its global x lies in [x_lo, x_hi]); a single domain is the case
+   * x_shift = 0, x_lo = x_m - 1, x_hi = x_M + 1. */
   const long sx = nyp * nzp, sy = nzp;
+  (void)x_m; (void)x_M;
   for (int p = p_src_m; p <= p_src_M; p += 1)
     for (int rx = 0; rx <= 1; rx += 1)
       for (int ry = 0; ry <= 1; ry += 1)
@@ -323,13 +327,13 @@ static void oracle_section1_order(int H, const float *restrict m, const float *r
           const float gz = (-o_z + coords[p * coord_stride + 2]) / h_z;
           const int posx = (int)floorf(gx), posy = (int)floorf(gy), posz = (int)floorf(gz);
           const float px = -floorf(gx) + gx, py = -floorf(gy) + gy, pz = -floorf(gz) + gz;
-          if (rx + posx >= x_m - 1 && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
-              rx + posx <= x_M + 1 && ry + posy <= y_M + 1 && rz + posz <= z_M + 1) {
+          if (rx + posx >= x_lo && ry + posy >= y_m - 1 && rz + posz >= z_m - 1 &&
+              rx + posx <= x_hi && ry + posy <= y_M + 1 && rz + posz <= z_M + 1) {
             const float r0 = 1.0e-2F * (rx * px + (1 - rx) * (1 - px)) *
                              (ry * py + (1 - ry) * (1 - py)) * (rz * pz + (1 - rz) * (1 - pz)) *
                              src[(long)time * src_stride + p] /
-                             m[(long)(posx + H) * sx + (long)(posy + H) * sy + (posz + H)];
-            u2[(long)(rx + posx + H) * sx + (long)(ry + posy + H) * sy + (rz + posz + H)] += r0;
+                             m[(long)(posx - x_shift + H) * sx + (long)(posy + H) * sy + (posz + H)];
+            u2[(long)(rx + posx - x_shift + H) * sx + (long)(ry + posy + H) * sy + (rz + posz + H)] += r0;
           }
         }
 }
@@ -359,7 +363,7 @@ int Oracle_Kernel_SpaceOrder(FDTD_OPERATOR_ARGS, int order) {
     if (has_src)
       oracle_section1_order(order, m, src, coords, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M, z_m,
                             z_M, h_x, h_y, h_z, o_x, o_y, o_z, p_src_m, p_src_M, time, src_stride,
-                            coord_stride);
+                            coord_stride, 0, x_m - 1, x_M + 1);
     if (timed) {
       timers->section0 += b - a;
       timers->section1 += now_s() - b;
@@ -444,6 +448,61 @@ int Oracle_Kernel_Forward(struct dataobj *damp_vec, struct dataobj *m_vec, struc
   return 0;
 }
 
+/* oracle_section0_order with the damping term of the forward operator. */
+static void oracle_section0_order_damped(int order, const float *restrict m, const float *restrict damp,
+                                         const float *restrict u0, const float *restrict u1,
+                                         float *restrict u2, long nyp, long nzp, int x_m, int x_M, int y_m,
+                                         int y_M, int z_m, int z_M, float dt, float r0, float r1, float r2,
+                                         float r3, float r4) {
+  const int R = order / 2, H = order;
+  const float *w = k_order_weights[R - 2];
+  const long sx = nyp * nzp, sy = nzp;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int x = x_m; x <= x_M; x += 1)
+    for (int y = y_m; y <= y_M; y += 1)
+      for (int z = z_m; z <= z_M; z += 1) {
+        const long c = (long)(x + H) * sx + (long)(y + H) * sy + (z + H);
+        const float uc = u0[c];
+        const float r5 = w[0] * uc;
+        float dxx = r5, dyy = r5, dzz = r5;
+        for (int k = R; k >= 1; --k) {
+          dxx = dxx + w[k] * (u0[c - k * sx] + u0[c + k * sx]);
+          dyy = dyy + w[k] * (u0[c - k * sy] + u0[c + k * sy]);
+          dzz = dzz + w[k] * (u0[c - k] + u0[c + k]);
+        }
+        const float mc = m[c], dc = damp[c];
+        u2[c] = dt * dt *
+                (r2 * dxx + r3 * dyy + r4 * dzz - (-2.0F * r1 * uc + r1 * u1[c]) * mc + r0 * dc * uc) /
+                (mc + dt * dc);
+      }
+}
+
+/* Single sweeps at any space order on caller-chosen levels (damp may be NULL: no damping term), and the
+ * slab form of the scatter on arrays padded by H cells; used by the slab-decomposition tests. */
+void oracle_stencil_step_order(int order, const float *m, const float *damp, float *u, long nxp, long nyp,
+                               long nzp, int x_m, int x_M, int y_m, int y_M, int z_m, int z_M, float dt,
+                               float h_x, float h_y, float h_z, int t0, int t1, int t2) {
+  const long vol = nxp * nyp * nzp;
+  const float r0 = 1.0F / dt, r1 = 1.0F / (dt * dt), r2 = 1.0F / (h_x * h_x), r3 = 1.0F / (h_y * h_y),
+              r4 = 1.0F / (h_z * h_z);
+  if (damp)
+    oracle_section0_order_damped(order, m, damp, u + t0 * vol, u + t1 * vol, u + t2 * vol, nyp, nzp, x_m, x_M,
+                                 y_m, y_M, z_m, z_M, dt, r0, r1, r2, r3, r4);
+  else
+    oracle_section0_order(order, m, u + t0 * vol, u + t1 * vol, u + t2 * vol, nyp, nzp, x_m, x_M, y_m, y_M,
+                          z_m, z_M, dt, r1, r2, r3, r4);
+}
+
+void oracle_source_inject_slab_order(int H, const float *m, const float *src, const float *coords, float *u,
+                                     long nxp, long nyp, long nzp, int y_m, int y_M, int z_m, int z_M,
+                                     float h_x, float h_y, float h_z, float o_x, float o_y, float o_z,
+                                     int p_src_m, int p_src_M, int time, long src_stride, long coord_stride,
+                                     int t2, int x_shift, int x_lo, int x_hi) {
+  const long vol = nxp * nyp * nzp;
+  oracle_section1_order(H, m, src, coords, u + t2 * vol, nyp, nzp, 0, 0, y_m, y_M, z_m, z_M, h_x, h_y, h_z,
+                        o_x, o_y, o_z, p_src_m, p_src_M, time, src_stride, coord_stride, x_shift, x_lo, x_hi);
+}
+
 /* The same operator for space order 4 .. 12 on arrays padded by `order` cells per side: the generic
  * sweep of oracle_section0_order with the damping term, the scatter and the receivers on the wider
  * padding.  With order 4 it gives the bits of Oracle_Kernel_Forward (checked by the tests). */
@@ -459,8 +518,7 @@ int Oracle_Kernel_ForwardOrder(struct dataobj *damp_vec, struct dataobj *m_vec, 
                                int order) {
   (void)deviceid; (void)devicerm; (void)timers;
   if (order < 4 || order > 12 || order % 2) return 1;
-  const int R = order / 2, H = order;
-  const float *w = k_order_weights[R - 2];
+  const int H = order;
   const long nxp = u_vec->size[1], nyp = u_vec->size[2], nzp = u_vec->size[3];
   const long vol = nxp * nyp * nzp, sx = nyp * nzp, sy = nzp;
   float *u = (float *)u_vec->data;
@@ -475,28 +533,12 @@ int Oracle_Kernel_ForwardOrder(struct dataobj *damp_vec, struct dataobj *m_vec, 
     const int t0 = time % 3, t1 = (time + 2) % 3, t2 = (time + 1) % 3;
     const float *u0 = u + t0 * vol, *u1 = u + t1 * vol;
     float *u2 = u + t2 * vol;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int x = x_m; x <= x_M; x += 1)
-      for (int y = y_m; y <= y_M; y += 1)
-        for (int z = z_m; z <= z_M; z += 1) {
-          const long c = (long)(x + H) * sx + (long)(y + H) * sy + (z + H);
-          const float uc = u0[c];
-          const float r5 = w[0] * uc;
-          float dxx = r5, dyy = r5, dzz = r5;
-          for (int k = R; k >= 1; --k) {
-            dxx = dxx + w[k] * (u0[c - k * sx] + u0[c + k * sx]);
-            dyy = dyy + w[k] * (u0[c - k * sy] + u0[c + k * sy]);
-            dzz = dzz + w[k] * (u0[c - k] + u0[c + k]);
-          }
-          const float mc = m[c], dc = damp[c];
-          u2[c] = dt * dt *
-                  (r2 * dxx + r3 * dyy + r4 * dzz - (-2.0F * r1 * uc + r1 * u1[c]) * mc + r0 * dc * uc) /
-                  (mc + dt * dc);
-        }
+    oracle_section0_order_damped(order, m, damp, u0, u1, u2, nyp, nzp, x_m, x_M, y_m, y_M, z_m, z_M, dt,
+                                 r0, r1, r2, r3, r4);
     if (has_src)
       oracle_section1_order(H, m, src, scoords, u2, nyp, nzp, x_m, x_M, y_m, y_M, z_m, z_M, h_x, h_y,
                             h_z, o_x, o_y, o_z, p_src_m, p_src_M, time, src_vec->size[1],
-                            src_coords_vec->size[1]);
+                            src_coords_vec->size[1], 0, x_m - 1, x_M + 1);
     for (int p = p_rec_m; p <= p_rec_M; p += 1) {
       const long cs = rec_coords_vec->size[1];
       const float gx = (-o_x + rcoords[p * cs + 0]) / h_x, gy = (-o_y + rcoords[p * cs + 1]) / h_y,

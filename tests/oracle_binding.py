@@ -39,6 +39,13 @@ def oracle():
         L.oracle_source_inject_slab.restype = None
         L.oracle_source_inject_slab_mode.argtypes = L.oracle_source_inject_slab.argtypes + [C.c_int] * 3
         L.oracle_source_inject_slab_mode.restype = None
+        L.oracle_stencil_step_order.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_long] * 3
+                                                + [C.c_int] * 6 + [C.c_float] * 4 + [C.c_int] * 3)
+        L.oracle_stencil_step_order.restype = None
+        L.oracle_source_inject_slab_order.argtypes = ([C.c_int] + [C.c_void_p] * 4 + [C.c_long] * 3 + [C.c_int] * 4
+                                                      + [C.c_float] * 6 + [C.c_int] * 3 + [C.c_long] * 2
+                                                      + [C.c_int] * 4)
+        L.oracle_source_inject_slab_order.restype = None
         L.Oracle_Kernel_SpaceOrder.argtypes = pkg.abi.OPERATOR_ARGTYPES + [C.c_int]
         L.Oracle_Kernel_SpaceOrder.restype = C.c_int
         L.Oracle_Kernel_Forward.argtypes = pkg.abi.FORWARD_ARGTYPES

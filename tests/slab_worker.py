@@ -32,6 +32,7 @@ class OracleStepper:
         self.p = prop
         self.u = prop.u.numpy()
         self.m = prop.m.numpy()
+        self.damp = None if getattr(prop, "damp", None) is None else prop.damp.numpy()
         self.src = prop.src.numpy() if prop.nsrc else None
         self.coords = prop.coords.numpy() if prop.nsrc else None
 
@@ -41,13 +42,27 @@ class OracleStepper:
     def stencil(self, x_lo, x_hi, t0, t1, t2, boundary):
         if x_hi < x_lo:
             return
-        nyp, nzp = self.u.shape[2:]
+        nxp, nyp, nzp = self.u.shape[1:]
+        H = self.p.halo
+        if H != HALO or self.damp is not None:      # the sweeps of the higher orders / with the damping term
+            self.ob.oracle().oracle_stencil_step_order(
+                H, self.m.ctypes.data, None if self.damp is None else self.damp.ctypes.data, self.u.ctypes.data,
+                nxp, nyp, nzp, x_lo, x_hi, 0, nyp - 2 * H - 1, 0, nzp - 2 * H - 1, float(np.float32(self.p.dt)),
+                *[float(np.float32(v)) for v in self.p.h], t0, t1, t2)
+            return
         self.ob.oracle_stencil_step(self.m, self.u, (x_lo, x_hi, 0, nyp - 9, 0, nzp - 9),
                                     np.float32(self.p.dt), tuple(np.float32(v) for v in self.p.h), t0, t1, t2)
 
     def inject(self, region, t2, time, boundary):
         p = self.p
         nxp, nyp, nzp = self.u.shape[1:]
+        H = p.halo
+        if H != HALO:
+            self.ob.oracle().oracle_source_inject_slab_order(
+                H, self.m.ctypes.data, self.src.ctypes.data, self.coords.ctypes.data, self.u.ctypes.data,
+                nxp, nyp, nzp, 0, nyp - 2 * H - 1, 0, nzp - 2 * H - 1, *[float(v) for v in p.h], *[float(v) for v in p.o],
+                0, p.nsrc - 1, time, self.src.shape[1], self.coords.shape[1], t2, p.x_off, region[0], region[1])
+            return
         self.ob.oracle().oracle_source_inject_slab(
             self.m.ctypes.data, self.src.ctypes.data, self.coords.ctypes.data, self.u.ctypes.data,
             nxp, nyp, nzp, 0, nyp - 9, 0, nzp - 9, *[float(v) for v in p.h], *[float(v) for v in p.o],
@@ -298,8 +313,47 @@ def self_neighbour_pair_run(name, outdir):
     sys.exit(0 if nbad == 0 else 1)
 
 
+def order_case(name):
+    """Cases of the one-step schedule beyond order 4 / with damping: "o<order>" or "o<order>_damped" — a random
+    field on arrays padded by the order, varying m, three sources (one in the outermost cell), a sponge."""
+    from test_forward_operator import sponge
+    from test_space_orders import padded_case
+    order = int(name[1:].split("_")[0])
+    n, nt = (26, 18, 40), 9
+    u, m, src, coords, kw = padded_case(order, n, nt, 3, 300 + order, None, True)
+    coords[1, 0] = 12.5 * kw["h"][0]      # corners in planes 12 | 13: the cut between two slabs of 13 planes
+    damp = sponge(m.shape, 5, 40.0, halo=order) if name.endswith("_damped") else None
+    return order, u, m, damp, src, coords, kw
+
+
+def order_run(kind, name, outdir):
+    """One rank of a one-step-per-exchange run at a space order above 4 and / or with the damping term."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank,
+                            world_size=world)
+    pkg = load_package()
+    order, u, m, damp, src, coords, kw = order_case(name)
+    NX = u.shape[1] - 2 * order
+    layout = pkg.slab.SlabLayout(NX, world, order=order)
+    dev = "cpu" if kind == "oracle_order" else torch.device("cuda", 0)
+    cut = lambda a, axis: torch.from_numpy(np.ascontiguousarray(layout.cut(a, rank, axis=axis))).to(dev)
+    u_t, m_t = cut(u, 1), cut(m, 0)
+    damp_t = None if damp is None else cut(damp, 0)
+    stepper = OracleStepper() if kind == "oracle_order" else pkg.slab.HipStepper(dev)
+    comm = pkg.slab.TorchComm(dist, rank, world, stepper)
+    prop = pkg.slab.SlabPropagator(layout, rank, u_t, m_t, torch.from_numpy(src).to(dev), torch.from_numpy(coords).to(dev),
+                                   dt=kw["dt"], h=kw["h"], o=(0.0, 0.0, 0.0), stepper=stepper, comm=comm, damp=damp_t)
+    assert prop.ghost == order // 2 and prop.overlap == (prop.nx >= order + 1)
+    prop.run(0, kw["time_M"])
+    np.save(os.path.join(outdir, f"u_rank{rank}.npy"), u_t.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     kind, name, outdir = sys.argv[1:4]
+    if kind in ("oracle_order", "hip_order"):
+        return order_run(kind, name, outdir)
     if kind == "nccl_self_pair":
         return self_neighbour_pair_run(name, outdir)
     if kind == "nccl_self":

@@ -45,6 +45,54 @@ def run_slabs(kind, name, world, tmp_path, pkg):
     return out
 
 
+def run_order_slabs(kind, name, world, tmp_path, pkg):
+    """A slab run of the one-step schedule at a space order above 4 and / or with the damping term, reassembled,
+    and the same case through the single-domain restatement."""
+    import oracle_binding as ob
+    from slab_worker import order_case
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(free_port()), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), kind, name,
+                                       str(tmp_path)], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    order, u, m, damp, src, coords, kw = order_case(name)
+    layout = pkg.slab.SlabLayout(u.shape[1] - 2 * order, world, order=order)
+    out = np.full_like(u, np.nan)
+    for rank in range(world):
+        layout.paste_owned(out, np.load(os.path.join(tmp_path, f"u_rank{rank}.npy")), rank, axis=1)
+    ref = u.copy()
+    if damp is None:
+        ob.run_oracle_order(order, m, src, coords, ref, **kw)
+    else:
+        rc, _ = pkg.run_forward(ob.forward_oracle_order(order), damp, m, None, None, src, coords, ref, h=kw["h"],
+                                dt=kw["dt"], bounds=kw["bounds"], time_M=kw["time_M"])
+        assert rc == 0
+    return out, ref
+
+
+# One step per exchange at the higher space orders (order / 2 ghost planes per side on arrays padded by the order) and
+# with the damping term of the forward operator: no reference arithmetic exists for either (parity unpinned); the
+# union of the slabs must be the single-domain restatement's bits.
+@pytest.mark.parametrize("name,world", [("o6", 2), ("o8", 2), ("o12", 2), ("o8", 3), ("o4_damped", 2), ("o8_damped", 2),
+                                        ("o12_damped", 3)])
+def test_slab_orders_and_damping_orchestration_cpu(pkg, tmp_path, name, world):
+    import oracle_binding as ob
+    out, ref = run_order_slabs("oracle_order", name, world, tmp_path, pkg)
+    assert ob.bits_equal(out, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("o6", 2), ("o8", 3), ("o12", 2), ("o4_damped", 2), ("o8_damped", 2)])
+def test_slab_orders_and_damping_hip_ranks_one_gpu(pkg, tmp_path, name, world):
+    """The same with the HIP kernels, several ranks sharing one GPU (ghosts staged through the host)."""
+    import oracle_binding as ob
+    out, ref = run_order_slabs("hip_order", name, world, tmp_path, pkg)
+    assert ob.bits_equal(out, ref)
+
+
 def test_layout_covers_every_plane_once(pkg):
     for NX, world in ((32, 2), (20, 3), (17, 4), (512, 8), (2048, 8)):
         lay = pkg.slab.SlabLayout(NX, world)
