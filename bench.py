@@ -79,6 +79,9 @@ def parse_args():
     ap.add_argument("--space-order", type=int, default=4, choices=[4, 6, 8, 10, 12],
                     help="space order of the stencil (main.cpp:27-32: arrays padded by that many cells); N = 1 only, "
                          "orders above 4 run one step per sweep through the library's time loop")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="N=1: skip the two counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around a short run of "
+                         "this same command in child processes) that measure roofline.traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="oracle steps for the CPU baseline sample")
     return ap.parse_args()
@@ -156,6 +159,65 @@ def library_source_hash():
         if name.endswith((".hip", ".h")):
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def measure_traffic(kernel_substr, launches_expected):
+    """HBM-side bytes per launch of the dominant kernel, measured now: two child processes run a short version of this
+    very command under `rocprofv3 --pmc`, one counter per pass (FETCH_SIZE, then WRITE_SIZE: the counter blocks do not
+    hold both), and the per-dispatch values of the kernel are averaged.  gfx950 counts a 128-byte read request as 64
+    bytes, so FETCH_SIZE is doubled; WRITE_SIZE is exact.  Returns a dict or None (no profiler, a pass failed)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None
+    argv = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
+    # strip the options this function sets itself
+    clean, skip = [], 0
+    for a in argv:
+        if skip:
+            skip -= 1
+            continue
+        if a in ("--steps", "--warmup", "--reps", "--cpu-steps"):
+            skip = 1
+            continue
+        if a.split("=")[0] in ("--steps", "--warmup", "--reps", "--cpu-steps"):
+            continue
+        clean.append(a)
+    child = [sys.executable, os.path.abspath(__file__)] + clean + ["--steps", "8", "--warmup", "2", "--reps", "1",
+                                                                  "--no-cpu-baseline", "--no-traffic"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="fdtd_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                p = subprocess.run(["timeout", "-s", "KILL", "150", prof, "--pmc", counter, "--output-format", "csv", "-d", d,
+                                    "--"] + child, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                   timeout=170)
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+            if p.returncode != 0 or not files:
+                return None
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(files[0]))
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not vals:
+                return None
+            out[counter + "_KB_per_launch"] = sum(vals) / len(vals)
+            out[counter + "_launches"] = len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["hbm_read_bytes_per_launch"] = 2 * 1024 * out["FETCH_SIZE_KB_per_launch"]
+    out["hbm_write_bytes_per_launch"] = 1024 * out["WRITE_SIZE_KB_per_launch"]
+    out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+    out["method"] = ("measured in this run: two child runs of this command (8 timed steps) under rocprofv3 --pmc, FETCH_SIZE "
+                     "and WRITE_SIZE in separate passes, averaged over the kernel's dispatches; FETCH_SIZE doubled (gfx950 "
+                     "counts a 128-byte request as 64 bytes)")
+    return out
 
 
 def cpu_baseline(pkg, n, steps):
@@ -477,14 +539,14 @@ def main():
         nx_loc = prop.layout.nx_loc(rank)
         own_cells = float(nx_loc) * n * n
         ms_step = stats(elapsed_reps)[0] / K * 1e3
-        if kernel_ms == kernel_ms and launch_cells > 0:
+        exchange = {
+            "ghost_bytes_per_side_per_step": (4 if pairs else 2) * (n + 8) * (n + 8) * 4 / (2 if pairs else 1),
+            "transport": "RCCL point-to-point" if backend == "nccl" else "gloo, host staged (rehearsal)",
+        }
+        if kernel_ms == kernel_ms and launch_cells > 0:      # (NaN: too few steps for a timed interior launch)
             sweep_ms_per_step = kernel_ms / updates_per_launch * own_cells / (launch_cells / updates_per_launch)
-            exchange = {
-                "exposed_ms_per_step": round(max(0.0, ms_step - sweep_ms_per_step), 4),
-                "sweep_only_ms_per_step": round(sweep_ms_per_step, 4),
-                "ghost_bytes_per_side_per_step": (4 if pairs else 2) * (n + 8) * (n + 8) * 4 / (2 if pairs else 1),
-                "transport": "RCCL point-to-point" if backend == "nccl" else "gloo, host staged (rehearsal)",
-            }
+            exchange["exposed_ms_per_step"] = round(max(0.0, ms_step - sweep_ms_per_step), 4)
+            exchange["sweep_only_ms_per_step"] = round(sweep_ms_per_step, 4)
         dist.destroy_process_group()
     else:
         ranks_seen = 1
@@ -653,8 +715,16 @@ def main():
     }
     # HBM bytes per launch from the PMC counters: measured in separate profiler passes
     # (tools/profile_bench.sh) and only valid for the kernel sources and workload they were taken on.
+    live = None
+    if not slabs and not args.no_traffic and not h16 and args.space_order == 4 and args.variant == "auto":
+        live = measure_traffic("stencil_march2" if updates_per_launch == 2 else "stencil_march_lds", K)
+    if live is not None:
+        roof["traffic"] = live["hbm_bytes_per_launch"]
+        roof["traffic_source"] = live
+        roof["physical_GBps"] = round(roof["traffic"] / (kernel_ms * 1e-3) / 1e9, 1)
+        roof["physical_frac"] = round(roof["physical_GBps"] / HBM_PEAK_GBS, 4)
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath) and not slabs:
+    if live is None and os.path.exists(tpath) and not slabs:
         try:
             tj = json.load(open(tpath))
             want = "stencil_march2" if updates_per_launch == 2 else "stencil_march_lds"

@@ -80,3 +80,41 @@ def test_bench_at_a_higher_space_order():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "8th-order" in out["config"]["workload"] and out["value"] > 0 and "cpu_baseline" not in out
     assert out["roofline"]["cell_updates_per_launch"] == 256 ** 3
+
+
+@pytest.mark.gpu
+def test_bench_peer_transport_in_one_process():
+    """--transport peer: the library's multi-device session, here two slabs on the one GPU; the line prices the
+    exchange against the same schedule without pushes and reports the host's issue time per pair."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FDTD_MULTIGPU_DEVICES"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--transport", "peer", "--slabs", "2", "--grid", "512", "--global-x", "128",
+                        "--steps", "6", "--warmup", "2", "--reps", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    ex = out["exchange"]
+    assert out["config"]["slabs"] == 2 and "128x512x512" in out["config"]["workload"] and out["value"] > 0
+    assert "hipMemcpyPeerAsync" in ex["transport"] and ex["issuing"] == "one host thread per slab"
+    for key in ("exposed_ms_per_step", "sweep_only_ms_per_step", "host_issue_us_per_pair", "one_issuing_thread"):
+        assert key in ex, key
+
+
+@pytest.mark.gpu
+def test_bench_both_transports_in_one_line():
+    """--transport both: the RCCL run (here the one-rank rehearsal with itself as neighbour) and the peer run, each in
+    a process of its own; one line, the peer run's figures under `exchange_peer`."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FDTD_MULTIGPU_DEVICES"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--self-exchange", "--transport", "both", "--slabs", "2",
+                        "--grid", "512", "--global-x", "128", "--steps", "12", "--warmup", "2", "--reps", "1",
+                        "--no-breakdown"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert "RCCL" in out["exchange"]["transport"]
+    assert "hipMemcpyPeerAsync" in out["exchange_peer"]["transport"] and out["exchange_peer"]["value"] > 0

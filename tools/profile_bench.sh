@@ -7,9 +7,9 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profile_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --reps 1 > $O/stats.log 2>&1 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --reps 1 --steps 10 > $O/fetch.log 2>&1 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --reps 1 --steps 10 > $O/write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-traffic --reps 1 > $O/stats.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --no-traffic --reps 1 --steps 10 > $O/fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --no-traffic --reps 1 --steps 10 > $O/write.log 2>&1 || exit 1
 python3 - "$O" "$R" <<'PY'
 import csv, glob, collections, hashlib, json, os, sys
 O, R = sys.argv[1], sys.argv[2]
