@@ -136,6 +136,8 @@ def lib():
                                                 C.c_int, C.c_int]
     L.fdtd_hip_multigpu_fill_standard_inputs.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.fdtd_hip_multigpu_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.fdtd_hip_multigpu_set_damping.argtypes = [C.c_void_p, C.c_void_p]
+    L.fdtd_hip_multigpu_set_damping.restype = C.c_int
     L.fdtd_hip_multigpu_advance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Profiler)]
     L.fdtd_hip_multigpu_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.fdtd_hip_multigpu_max_abs.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]
@@ -381,6 +383,9 @@ class MultiGpuSession:
     def upload(self, u, m, time_m=0):
         self._check(self.L.fdtd_hip_multigpu_upload(self.h, u.ctypes.data, None if m is None else m.ctypes.data, time_m),
                     "upload")
+
+    def set_damping(self, damp):
+        self._check(self.L.fdtd_hip_multigpu_set_damping(self.h, None if damp is None else damp.ctypes.data), "set_damping")
 
     def advance(self, time_m, time_M):
         prof = Profiler(0.0, 0.0)

@@ -92,6 +92,7 @@ struct Dev {
   int left = -1, right = -1;  // neighbour slabs (indices into the slab list), -1 = physical boundary
   float *lv[4] = {nullptr, nullptr, nullptr, nullptr};
   float *m = nullptr, *src = nullptr, *coords = nullptr, *scratch = nullptr;
+  float *damp = nullptr;        // damping field of the slab (fdtd_hip_multigpu_set_damping), else null
   unsigned *reduce = nullptr;   // two words for max_abs_kernel
   long scratch_floats = 0;
   size_t src_floats = 0, coords_floats = 0;
@@ -246,7 +247,7 @@ struct fdtd_multigpu {
     return fdtd_two_steps_impl(&g, v.m, v.src, v.coords, v.lv[op.cur], v.lv[op.prev], v.lv[op.third], v.lv[op.spare],
                                op.time, nsrc ? p_src_m : 0, nsrc ? p_src_M : -1, src_stride, coord_stride, variant, fl,
                                v.off, NX, st, nullptr, nullptr, use_scratch ? v.scratch : nullptr,
-                               use_scratch ? v.scratch_floats : 0);
+                               use_scratch ? v.scratch_floats : 0, v.damp);
   }
 
   // everything of one operation that a slab issues before its pushes
@@ -270,9 +271,19 @@ struct fdtd_multigpu {
       for (const Range &r : rs) {
         fdtd_geom g = v.g;
         g.x_m = r.lo; g.x_M = r.hi;
-        rc = fdtd_hip_one_step_slab(&g, v.m, v.src, v.coords, v.lv[op.cur], v.lv[op.prev], v.lv[op.third], op.time,
-                                    nsrc ? p_src_m : 0, nsrc ? p_src_M : -1, src_stride, coord_stride, FDTD_VARIANT_AUTO,
-                                    v.off, NX, r.boundary ? v.edge : v.inner);
+        hipStream_t st = r.boundary ? v.edge : v.inner;
+        if (v.damp) {   // the damped sweep, then the scatter of the planes this range owns (as fdtd_hip_one_step_slab)
+          rc = fdtd_stencil_levels_damped(&g, v.m, v.damp, v.lv[op.cur], v.lv[op.prev], v.lv[op.third], FDTD_STENCIL_ORDER, st);
+          if (!rc && nsrc) {
+            const int own_lo = r.lo + v.off == 0 ? -1 : r.lo + v.off, own_hi = r.hi + v.off == NX - 1 ? NX : r.hi + v.off;
+            rc = fdtd_inject_level(&g, v.m, v.src, v.coords, v.lv[op.third], op.time, p_src_m, p_src_M, src_stride,
+                                   coord_stride, v.off, own_lo, own_hi, 0, 0, 0, st);
+          }
+        } else {
+          rc = fdtd_hip_one_step_slab(&g, v.m, v.src, v.coords, v.lv[op.cur], v.lv[op.prev], v.lv[op.third], op.time,
+                                      nsrc ? p_src_m : 0, nsrc ? p_src_M : -1, src_stride, coord_stride,
+                                      FDTD_VARIANT_AUTO, v.off, NX, st);
+        }
         if (rc) return rc;
         if (!r.boundary) {
           FDTD_HIP_CHECK(hipEventRecord(v.ev_interior, v.inner));
@@ -464,7 +475,7 @@ struct fdtd_multigpu {
         if (s) (void)hipStreamSynchronize(s);
       for (float *p : v.lv)
         if (p) (void)hipFree(p);
-      for (void *p : {(void *)v.m, (void *)v.src, (void *)v.coords, (void *)v.scratch, (void *)v.reduce})
+      for (void *p : {(void *)v.m, (void *)v.src, (void *)v.coords, (void *)v.scratch, (void *)v.reduce, (void *)v.damp})
         if (p) (void)hipFree(p);
       for (hipStream_t s : {v.inner, v.edge, v.copy})
         if (s) (void)hipStreamDestroy(s);
@@ -613,6 +624,27 @@ extern "C" int fdtd_hip_multigpu_set_sources(fdtd_multigpu *h, const float *src,
   if (!h) return (int)hipErrorInvalidValue;
   DeviceGuard guard;
   return set_sources_impl(h, src, src_steps, src_stride, src_coords, coord_rows, coord_stride, p_src_m, p_src_M);
+}
+
+// The damping field of the forward operator (fdtd_forward.hip; host array of the padded shape of m), cut into
+// the slabs: every later advance runs the damped update (two damped steps per sweep where the sweep is fused).
+// NULL takes it away again.  No reference arithmetic exists for the damped update: parity unpinned.
+extern "C" int fdtd_hip_multigpu_set_damping(fdtd_multigpu *h, const float *damp) {
+  if (!h) return (int)hipErrorInvalidValue;
+  DeviceGuard guard;
+  const size_t plane = h->plane;
+  auto up = [&](Dev &v) -> int {
+    FDTD_HIP_CHECK(hipSetDevice(v.id));
+    const size_t lvol = (size_t)(v.nx + 2 * FDTD_HALO) * plane;
+    if (!damp) {
+      if (v.damp) FDTD_HIP_CHECK(hipFree(v.damp));
+      v.damp = nullptr;
+      return 0;
+    }
+    if (!v.damp) FDTD_HIP_CHECK(hipMalloc((void **)&v.damp, lvol * sizeof(float)));
+    return staged_copier_for_current_device().to_device(v.damp, damp + (size_t)v.off * plane, lvol * sizeof(float));
+  };
+  return h->for_each_slab(up, h->devices_distinct());
 }
 
 // The benchmark inputs of main.cpp:345-356 made on the devices: u = 0, m = 1.5 over the padded volume,

@@ -396,6 +396,9 @@ int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const floa
  *            sources of nt samples at the positions of main.cpp:301-325) made on the devices; time index 0.
  *   upload   host u[3][nxp][nyp][nzp] (the reference's ring at time index time_m) and m[nxp][nyp][nzp]
  *            (NULL: keep the model already there) cut into the slabs.
+ *   set_damping  the damping field of Kernel_HIP_Forward (host array of the padded shape of m; NULL: none): every
+ *            later advance runs the damped update, two damped steps per sweep where the sweep is fused (parity
+ *            unpinned, like Kernel_HIP_Forward).
  *   advance  steps time_m .. time_M inclusive; time_m must be the time index the session stands at (the
  *            one given to upload, 0 after fill, time_M + 1 of the previous advance).  Two steps per exchange,
  *            one single step at the end of an odd count.  Returns when every device has finished;
@@ -418,6 +421,7 @@ int fdtd_hip_multigpu_set_sources(fdtd_multigpu *h, const float *src, int src_st
                                   int p_src_m, int p_src_M);
 int fdtd_hip_multigpu_fill_standard_inputs(fdtd_multigpu *h, int nt, int nsrc);
 int fdtd_hip_multigpu_upload(fdtd_multigpu *h, const float *u, const float *m, int time_m);
+int fdtd_hip_multigpu_set_damping(fdtd_multigpu *h, const float *damp);
 int fdtd_hip_multigpu_advance(fdtd_multigpu *h, int time_m, int time_M, struct profiler *timers);
 int fdtd_hip_multigpu_gather(fdtd_multigpu *h, int ring_slot, float *host_level);
 int fdtd_hip_multigpu_max_abs(fdtd_multigpu *h, float *max_abs, long *nonfinite);

@@ -89,6 +89,41 @@ def test_session_upload_time_offset_and_halos(pkg, hiplib):
     assert ob.bits_equal(got, ref)
 
 
+@pytest.mark.parametrize("n,slabs,zone_fused", [((72, 64, 512), 3, "0"), ((72, 64, 512), 3, "1"), ((40, 24, 64), 3, "0")])
+def test_session_with_damping(pkg, hiplib, n, slabs, zone_fused, monkeypatch):
+    """The damped update through the session: two damped steps per sweep on the interior of each slab, boundary zones
+    through scratch or through the sweep itself, single damped steps at the end of odd counts (small box: everything
+    single-sweep pairs); against the forward operator's restatement (no reference arithmetic: parity unpinned)."""
+    from test_forward_operator import sponge
+    monkeypatch.setenv("FDTD_SLAB_ZONE_FUSED", zone_fused)
+    nt = 13
+    u0, m, src, coords = pkg.standard_inputs(*n, nt, 2)
+    rng = np.random.default_rng(17)
+    u0[:] = rng.uniform(-1, 1, size=u0.shape).astype(np.float32)
+    m[:] = rng.uniform(1, 3, size=m.shape).astype(np.float32)
+    damp = sponge(m.shape, 6, 40.0)
+    ref = u0.copy()
+    rc, _ = pkg.run_forward(ob.oracle().Oracle_Kernel_Forward, damp, m, None, None, src, coords, ref)
+    assert rc == 0
+    with pkg.MultiGpuSession(_geom(pkg, n), [0] * slabs) as s:
+        s.set_sources(src, coords)
+        s.set_damping(damp)
+        s.upload(u0, m, 0)
+        s.advance(0, 6)
+        s.advance(7, nt - 1)
+        got = np.empty_like(u0)
+        s.gather(got)
+        assert ob.bits_equal(got, ref)
+        # without the damping field the same session runs the plain update again
+        s.set_damping(None)
+        s.upload(u0, m, 0)
+        s.advance(0, nt - 1)
+        s.gather(got)
+    plain = u0.copy()
+    ob.run_oracle(m, src, coords, plain)
+    assert ob.bits_equal(got, plain)
+
+
 def test_session_rejects_bad_arguments(pkg, hiplib):
     n = (32, 16, 64)
     g = _geom(pkg, n)
