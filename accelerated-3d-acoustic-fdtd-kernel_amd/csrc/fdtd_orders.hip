@@ -306,6 +306,207 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// The marching sweep of radius 2, 3 and 4 in the shape of the order-4 marching kernel
+// (stencil_march_lds_kernel, fdtd_kernels.hip), for rows of whole float4s (z_m and the z extent
+// multiples of 4).  A wave owns RY = 2 rows x 256 cells (one float4 per lane) and marches along x;
+// 8 waves are stacked in y.
+//   x-neighbours: a register column of the 2R+1 planes p-R .. p+R of the owned rows.
+//   z-neighbours: the float4 of the previous / next lane by DPP wavefront shifts (4 cells reach up to
+//     R = 4); lane 0 / the last owned lane take them from a 16-byte edge load.
+//   y-neighbours: the waves publish the centre plane of their rows to LDS (double-buffered, one
+//     barrier per plane); the R rows either side of the 16-row tile are fetched by the waves at the
+//     ends of the stack, at the plane step at which the neighbouring tile fetches them as its own
+//     (p + R), and wait in a queue of R planes until their plane is the centre: one of the two
+//     requests hits in L2.
+// gfx950 retires loads and stores through one in-order counter, so an iteration first issues every
+// load the next iteration needs into one of two register sets (the loop is unrolled twice, the sets
+// alternate), then computes from the other set, then stores; no memory instruction sits under a
+// divergent branch.  u(t-1), m, the damping field and the result carry non-temporal hints.
+// One workgroup per CU, XCD-contiguous tile map, launches of whole rounds of workgroups (below).
+// Same arithmetic and operand order as the kernels above: same bits.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_prev_lane(float edge, float v) {   // lane i <- lane i-1; lane 0 keeps `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_next_lane(float edge, float v) {   // lane i <- lane i+1; lane 63 keeps `edge`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v),
+                                                               0x130, 0xf, 0xf, false));
+}
+template <bool NT>
+__device__ __forceinline__ f32x4 ldq_stream(const float *p) {
+  if constexpr (NT) return __builtin_nontemporal_load((const f32x4_a4 *)p);
+  else return ldq(p);
+}
+
+template <bool DAMPED>
+struct ColumnSet {            // what one plane step loads ahead
+  f32x4 col[2];               // u(t), plane p+R (relative to the plane the set is current for)
+  f32x4 prev[2], med[2];      // u(t-1), m of the current plane
+  f32x4 dmp[DAMPED ? 2 : 1];  // damping field of the current plane
+  f32x4 edge[2], edge_r[2];   // z-edge cells of the current plane: (z-4 .. z-1); full tiles: lane 63 holds (z+4 .. z+7)
+  f32x4 halo;                 // one row outside the tile, plane p+R (loader waves)
+};
+
+template <int R, bool NT, bool FULL, bool DAMPED>
+__global__ __launch_bounds__(512) void stencil_column_march_kernel(StencilArgs a, int xchunk, int nzt, int nyt,
+                                                                   DampTerm dm) {
+  static_assert(R >= 2 && R <= 4, "the neighbouring lane's float4 covers a radius of up to 4");
+  constexpr int RY = 2, NW = 8, TY = RY * NW, H = 2 * R, TZ = 256;
+  __shared__ f32x4 plane[2][TY + 2 * R][64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nzt * nyt);
+  const int yb = a.y_m + yt * TY, y0 = yb + wave * RY;
+  const int zfirst = a.z_m + zt * TZ + lane * 4;
+  // the z extent is a multiple of 4: a lane owns all of its cells or none.  Partial tiles: lanes behind the
+  // last owned one repeat its address, and a second edge load gives the last owned lane its right-hand cells.
+  const bool owned = FULL ? true : (zfirst <= a.z_M);
+  const int zload = FULL ? zfirst : min(zfirst, a.z_M - 3);
+  const bool last_owned = (lane == 63) || (!FULL && owned && zfirst + 4 > a.z_M);
+  const int x_begin = a.x_m + xc * xchunk, x_end = min(x_begin + xchunk - 1, a.x_M);
+  if (x_begin > x_end) return;
+  const unsigned sy = (unsigned)a.sy;
+  const long sx = a.sx;
+
+  unsigned voff[RY], veoff[RY];   // lane offsets (cells) inside a plane; rows past y_M + R repeat a readable row
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+    const int y = FULL ? (y0 + r) : min(y0 + r, a.y_M + R);
+    voff[r] = (unsigned)(y + H) * sy + (unsigned)(zload + H);
+    veoff[r] = (FULL && lane == 63) ? voff[r] + 4 : voff[r] - 4;   // (z+4 .. z+7) or (z-4 .. z-1)
+  }
+  // the waves at the ends of the stack also fetch one row outside the tile each
+  const bool halo_loader = (wave < R) || (wave >= NW - R);
+  const int halo_y = (wave < R) ? yb - R + wave
+                                : ((wave >= NW - R) ? min(yb + TY + (wave - (NW - R)), a.y_M + R) : min(y0, a.y_M + R));
+  const int halo_slot = (wave < R) ? wave : TY + R + (wave - (NW - R));
+  const unsigned vhoff = (unsigned)(halo_y + H) * sy + (unsigned)(zload + H);
+
+  const float *pu0 = a.u0 + (long)(x_begin + H) * sx;
+  const float *pu1 = a.u1 + (long)(x_begin + H) * sx;
+  const float *pm = a.m + (long)(x_begin + H) * sx;
+  const float *pd = DAMPED ? dm.damp + (long)(x_begin + H) * sx : nullptr;
+  float *pu2 = a.u2 + (long)(x_begin + H) * sx;
+
+  f32x4 col[2 * R][RY];   // planes p-R .. p+R-1 of the owned rows
+  f32x4 hq[R];            // the outside row at planes p .. p+R-1
+  ColumnSet<DAMPED> sa, sb;
+#pragma unroll
+  for (int r = 0; r < RY; ++r) {
+#pragma unroll
+    for (int p = 0; p < 2 * R; ++p) col[p][r] = ldq(pu0 + (long)(p - R) * sx + voff[r]);
+    sa.col[r] = ldq(pu0 + (long)R * sx + voff[r]);
+    sa.prev[r] = ldq_stream<NT>(pu1 + voff[r]);
+    sa.med[r] = ldq_stream<NT>(pm + voff[r]);
+    if (DAMPED) sa.dmp[r] = ldq_stream<NT>(pd + voff[r]);
+    sa.edge[r] = ldq(pu0 + veoff[r]);
+    if (!FULL) sa.edge_r[r] = ldq(pu0 + voff[r] + 4);
+  }
+  sa.halo = f32x4{0, 0, 0, 0};
+  sb.halo = f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < R; ++j) hq[j] = f32x4{0, 0, 0, 0};
+  if (halo_loader) {   // wave-uniform
+#pragma unroll
+    for (int j = 0; j < R; ++j) hq[j] = ldq(pu0 + (long)j * sx + vhoff);
+    sa.halo = ldq(pu0 + (long)R * sx + vhoff);
+  }
+  const float neg2r1 = -2.0F * a.r1;
+
+  // One plane.  `cur` was loaded during the previous iteration; `nxt` is filled now.
+  auto iteration = [&](int x, int buf, const ColumnSet<DAMPED> &cur, ColumnSet<DAMPED> &nxt) __attribute__((always_inline)) {
+    // ---- loads for plane x+1 (repeated on plane x at the end of the chunk) ----
+    const long step = x < x_end ? sx : 0;
+    const float *q0 = pu0 + step, *q1 = pu1 + step, *qm = pm + step, *qd = DAMPED ? pd + step : nullptr;
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      nxt.col[r] = ldq(q0 + (long)R * sx + voff[r]);
+      nxt.prev[r] = ldq_stream<NT>(q1 + voff[r]);
+      nxt.med[r] = ldq_stream<NT>(qm + voff[r]);
+      if (DAMPED) nxt.dmp[r] = ldq_stream<NT>(qd + voff[r]);
+      nxt.edge[r] = ldq(q0 + veoff[r]);
+      if (!FULL) nxt.edge_r[r] = ldq(q0 + voff[r] + 4);
+    }
+    if (halo_loader) nxt.halo = ldq(q0 + (long)R * sx + vhoff);
+
+    // ---- publish the centre plane of the owned rows (and the outside row) ----
+#pragma unroll
+    for (int r = 0; r < RY; ++r) plane[buf][wave * RY + r + R][lane] = col[R][r];
+    if (halo_loader) plane[buf][halo_slot][lane] = hq[0];
+    __syncthreads();
+    f32x4 cen[RY + 2 * R];
+#pragma unroll
+    for (int j = 0; j < RY + 2 * R; ++j)
+      cen[j] = (j >= R && j < R + RY) ? col[R][j - R] : plane[buf][wave * RY + j][lane];
+
+    // ---- compute and store plane x ----
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const f32x4 uc = cen[r + R];
+      // the cells before and behind the lane's four
+      f32x4 lo = f32x4{dpp_prev_lane(cur.edge[r].x, uc.x), dpp_prev_lane(cur.edge[r].y, uc.y),
+                       dpp_prev_lane(cur.edge[r].z, uc.z), dpp_prev_lane(cur.edge[r].w, uc.w)};
+      const f32x4 er = FULL ? cur.edge[r] : cur.edge_r[r];
+      f32x4 hi = f32x4{dpp_next_lane(er.x, uc.x), dpp_next_lane(er.y, uc.y), dpp_next_lane(er.z, uc.z),
+                       dpp_next_lane(er.w, uc.w)};
+      if (!FULL) hi = last_owned ? er : hi;
+      const float win[12] = {lo.x, lo.y, lo.z, lo.w, uc.x, uc.y, uc.z, uc.w, hi.x, hi.y, hi.z, hi.w};
+      const f32x4 r5 = Weights<R>::w[0] * uc;
+      f32x4 dxx = r5, dyy = r5, dzz = r5;
+#pragma unroll
+      for (int k = R; k >= 1; --k) {
+        const float w = Weights<R>::w[k];
+        const f32x4 xp = k == R ? cur.col[r] : col[R + k][r];
+        dxx = dxx + w * (col[R - k][r] + xp);
+        dyy = dyy + w * (cen[r + R - k] + cen[r + R + k]);
+        const f32x4 zm = f32x4{win[4 - k], win[5 - k], win[6 - k], win[7 - k]};
+        const f32x4 zp = f32x4{win[4 + k], win[5 + k], win[6 + k], win[7 + k]};
+        dzz = dzz + w * (zm + zp);
+      }
+      const f32x4 mc = cur.med[r];
+      f32x4 o;
+      if (DAMPED) {
+        const f32x4 dc = cur.dmp[r];
+        const f32x4 num =
+            a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * cur.prev[r]) * mc + dm.r0 * dc * uc);
+        const f32x4 den = mc + dm.dt * dc;
+        o = f32x4{num.x / den.x, num.y / den.y, num.z / den.z, num.w / den.w};
+      } else {
+        const f32x4 num = a.dt2 * (a.r2 * dxx + a.r3 * dyy + a.r4 * dzz - (neg2r1 * uc + a.r1 * cur.prev[r]) * mc);
+        o = f32x4{num.x / mc.x, num.y / mc.y, num.z / mc.z, num.w / mc.w};
+      }
+      if (FULL || (owned && y0 + r <= a.y_M)) {
+        if (NT) __builtin_nontemporal_store(o, (f32x4_a4 *)(pu2 + voff[r]));
+        else *(f32x4_a4 *)(pu2 + voff[r]) = o;
+      }
+    }
+
+    // ---- advance: shift the older planes, step the plane pointers ----
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+#pragma unroll
+      for (int p = 0; p + 1 < 2 * R; ++p) col[p][r] = col[p + 1][r];
+      col[2 * R - 1][r] = cur.col[r];
+    }
+#pragma unroll
+    for (int j = 0; j + 1 < R; ++j) hq[j] = hq[j + 1];
+    hq[R - 1] = cur.halo;
+    pu0 += sx; pu1 += sx; pm += sx; pu2 += sx;
+    if (DAMPED) pd += sx;
+  };
+
+  for (int x = x_begin; x <= x_end; x += 2) {
+    iteration(x, 0, sa, sb);
+    if (x + 1 > x_end) break;
+    iteration(x + 1, 1, sb, sa);
+  }
+}
+
 int g_space_order = 0;   // 0: not set yet (FDTD_STENCIL_ORDER, else 4)
 // The order of the call in progress on this thread (the *_order / Kernel_HIP_SpaceOrder entry points): it
 // takes precedence over the process-wide setting, so those entry points neither read nor change it.
@@ -343,24 +544,86 @@ void launch_order_march(const StencilArgs &a, hipStream_t s, DampTerm dm = DampT
   const long slots = (long)cus * march_workgroups_per_cu<R, RW, D, NT, DAMPED, LPR>();
   // x-chunks: the device works through ceil(workgroups / slots) rounds of (chunk length + lead-in), where
   // the lead-in — the 2R planes a chunk loads before its first result, without arithmetic — counts as R
-  // planes.  Take the number of chunks that minimises the product.
+  // planes.  Take the number of chunks that minimises the product, with chunks of at most 128 planes (64
+  // where a plane has 100 tiles or more): workgroups that march further drift apart and stop finding their
+  // neighbours' rows in L2.  Where the tiles of a plane fill rounds of resident workgroups exactly, every round
+  // is a launch of its own, so that the workgroups of a launch start together (1024^3 at order 8: 333 against
+  // 298 Gcells/s in one launch); where they do not, one launch fills the partial rounds by itself (768^3, 144
+  // tiles against 512 resident workgroups: 290 against 234 with a launch per round).
+  const int lcap = env_int_orders("FDTD_ORDER_LCAP", tiles >= 100 ? 64 : 128);
   long nchunks = 1;
   double best = 0.0;
+  bool have = false;
   for (long n = 1; n <= ex && n <= 4096; ++n) {
     const long len = (ex + n - 1) / n;
     if (n > 1 && len < 4) break;
+    if (len > lcap && len > 4) continue;
     const long rounds = (tiles * ((ex + len - 1) / len) + slots - 1) / slots;
     const double cost = (double)rounds * (double)(len + R + 1);
-    if (n == 1 || cost < best) {
+    if (!have || cost < best) {
       best = cost;
       nchunks = n;
+      have = true;
     }
   }
   const int forced = env_int_orders("FDTD_ORDER_XCHUNK", 0);
   const int xchunk = forced > 0 ? forced : (int)((ex + nchunks - 1) / nchunks);
   nchunks = (ex + xchunk - 1) / xchunk;
-  hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT, DAMPED, LPR>), dim3((unsigned)(tiles * nchunks)), dim3(512), 0, s,
-                     a, xchunk, nyt, nzt, dm);
+  long per_launch = nchunks;         // x-chunks per launch
+  if (tiles <= slots && slots % tiles == 0 && !env_int_orders("FDTD_ORDER_ONE_LAUNCH", 0)) per_launch = slots / tiles;
+  StencilArgs al = a;
+  for (long c0 = 0; c0 < nchunks; c0 += per_launch) {
+    const long nc = nchunks - c0 < per_launch ? nchunks - c0 : per_launch;
+    al.x_m = a.x_m + (int)(c0 * xchunk);
+    al.x_M = (int)(al.x_m + nc * xchunk - 1 < a.x_M ? al.x_m + nc * xchunk - 1 : a.x_M);
+    hipLaunchKernelGGL((stencil_order_march_kernel<R, RW, D, NT, DAMPED, LPR>), dim3((unsigned)(tiles * nc)), dim3(512), 0, s,
+                       al, xchunk, nyt, nzt, dm);
+  }
+}
+
+// Launch shape of stencil_column_march_kernel: one workgroup per CU at a time, so a launch runs in rounds of
+// 256 workgroups and is fastest when its workgroups advance plane by plane together; marches longer than
+// ~128 planes drift apart, so long grids are cut into several launches (as for the order-4 marching kernel).
+// Among the candidates the score prefers full rounds, then longer chunks (each chunk loads 2R planes before
+// its first result).
+template <int R, bool NT, bool DAMPED>
+void launch_column_march(const StencilArgs &a0, hipStream_t s, DampTerm dm) {
+  constexpr int TY = 16, TZ = 256;
+  const int ex = a0.x_M - a0.x_m + 1, ey = a0.y_M - a0.y_m + 1, ez = a0.z_M - a0.z_m + 1;
+  const int nzt = (ez + TZ - 1) / TZ, nyt = (ey + TY - 1) / TY;
+  const long tiles = (long)nzt * nyt, cus = 256;
+  const int lcap = env_int_orders("FDTD_ORDER_LCAP", tiles >= 100 ? 64 : 128);
+  int xchunk = ex < lcap ? ex : lcap, chunks = 1;
+  const int forced = env_int_orders("FDTD_ORDER_XCHUNK", 0);
+  if (forced > 0) {
+    xchunk = forced > ex ? ex : forced;
+    chunks = (ex + xchunk - 1) / xchunk;
+  } else {
+    double best = -1.0;
+    for (int c = 1; c <= 64; ++c) {
+      int xc = (ex + c - 1) / c;
+      if (xc > lcap) xc = lcap;
+      if (xc < 8 && c > 1) break;
+      const long blocks = (long)c * tiles, rounds = (blocks + cus - 1) / cus;
+      const double fill = (double)blocks / (double)(rounds * cus);
+      const double score = fill * (double)xc / (double)(xc + 2 * R + 2);
+      if (score > best + 1e-9) { best = score; xchunk = xc; chunks = c; }
+    }
+    const long per = (long)chunks * xchunk, launches = (ex + per - 1) / per, planes = (ex + launches - 1) / launches;
+    xchunk = (int)((planes + chunks - 1) / chunks);
+    if (xchunk < 1) xchunk = 1;
+  }
+  const bool full = (ez % TZ == 0) && (ey % TY == 0);
+  StencilArgs a = a0;
+  const long per_launch = (long)chunks * xchunk;
+  for (long x0 = a0.x_m; x0 <= a0.x_M; x0 += per_launch) {
+    a.x_m = (int)x0;
+    a.x_M = (int)((x0 + per_launch - 1 < a0.x_M) ? x0 + per_launch - 1 : a0.x_M);
+    const int nxc = (a.x_M - a.x_m + xchunk) / xchunk;
+    const dim3 grid((unsigned)(tiles * nxc));
+    if (full) hipLaunchKernelGGL((stencil_column_march_kernel<R, NT, true, DAMPED>), grid, dim3(512), 0, s, a, xchunk, nzt, nyt, dm);
+    else hipLaunchKernelGGL((stencil_column_march_kernel<R, NT, false, DAMPED>), grid, dim3(512), 0, s, a, xchunk, nzt, nyt, dm);
+  }
 }
 
 // The marching sweep takes boxes that stay inside the interior of the arrays (its 16-byte accesses reach up
@@ -440,6 +703,25 @@ static int sweep_order(const struct fdtd_geom *g, const float *m, const float *d
     // rows that fill multiples of 128 cells better than multiples of 256 (384 = 3 x 128): half a wave per row
     const int lpr_auto = ((ez + 127) / 128) * 128 < ((ez + 255) / 256) * 256 ? 32 : 64;
     const int lpr = env_int_orders("FDTD_ORDER_LPR", lpr_auto) == 32 ? 32 : 64;
+    // rows of whole float4s, radius up to 4, tiles of 256 cells: the register-column sweep (FDTD_ORDER_COLUMN=0:
+    // the plane-in-LDS sweep below for every radius)
+    if (R <= env_int_orders("FDTD_ORDER_COLUMN_MAX_R", 3) && R <= 4 && lpr == 64 && g->z_m % 4 == 0 && ez % 4 == 0 &&
+        env_int_orders("FDTD_ORDER_COLUMN", 1) != 0) {
+#define ORDER_COLUMN(R_)                                                            \
+  case R_:                                                                          \
+    if (damp) launch_column_march<R_, true, true>(a, s, dm);                        \
+    else if (nt) launch_column_march<R_, true, false>(a, s, dm);                    \
+    else launch_column_march<R_, false, false>(a, s, dm);                           \
+    break;
+      switch (R) {
+        ORDER_COLUMN(2)
+        ORDER_COLUMN(3)
+        default:
+        ORDER_COLUMN(4)
+      }
+#undef ORDER_COLUMN
+      return (int)hipGetLastError();
+    }
 #define ORDER_MARCH(R_)                                                                    \
   case R_:                                                                                 \
     if (damp && lpr == 32) launch_order_march<R_, 2, 1, true, true, 32>(a, s, dm);         \
