@@ -141,6 +141,8 @@ def lib():
     L.fdtd_hip_multigpu_advance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Profiler)]
     L.fdtd_hip_multigpu_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.fdtd_hip_multigpu_max_abs.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_long)]
+    L.fdtd_hip_multigpu_checksum.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+    L.fdtd_hip_multigpu_checksum.restype = C.c_int
     L.fdtd_hip_multigpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double * 10), C.c_int]
     for name in ("create", "destroy", "set_sources", "fill_standard_inputs", "upload", "advance", "gather", "max_abs",
                  "stats"):
@@ -401,6 +403,15 @@ class MultiGpuSession:
         mx, bad = C.c_float(0.0), C.c_long(0)
         self._check(self.L.fdtd_hip_multigpu_max_abs(self.h, C.byref(mx), C.byref(bad)), "max_abs")
         return mx.value, bad.value
+
+    def checksum(self):
+        """64-bit word sums of the three ring slots."""
+        out = []
+        for slot in range(3):
+            v = C.c_ulonglong(0)
+            self._check(self.L.fdtd_hip_multigpu_checksum(self.h, slot, C.byref(v)), "checksum")
+            out.append(v.value)
+        return out
 
     def stats(self, reset=False):
         out = (C.c_double * 10)()

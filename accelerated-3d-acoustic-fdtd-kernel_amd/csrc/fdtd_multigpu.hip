@@ -86,6 +86,16 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const float *p, size_t n, 
   }
 }
 
+// sum of n 32-bit words as a 64-bit integer (wraps; independent of the order of the additions, hence of how the
+// domain is cut into slabs): a checksum that two runs of the same inputs can be compared by
+__global__ __launch_bounds__(256) void word_sum_kernel(const unsigned *p, size_t n, unsigned long long *out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += p[i];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 struct Dev {
   int id = 0;                 // HIP device
   int nx = 0, off = 0;        // owned planes and the first of them (interior index)
@@ -820,6 +830,31 @@ extern "C" int fdtd_hip_multigpu_max_abs(fdtd_multigpu *h, float *max_abs, long 
   }
   if (max_abs) memcpy(max_abs, &best, sizeof(float));
   if (nonfinite) *nonfinite = bad;
+  return 0;
+}
+
+// Sum of all 32-bit words of one ring slot's level (owned planes of every slab, padding in y and z included) as a
+// 64-bit integer: the same for every decomposition of the same run, so a run on 8 slabs can be compared with the
+// undivided one without either field leaving the devices.
+extern "C" int fdtd_hip_multigpu_checksum(fdtd_multigpu *h, int ring_slot, unsigned long long *sum) {
+  if (!h || !sum || ring_slot < 0 || ring_slot > 2 || !h->fields_set || h->poisoned) return (int)hipErrorInvalidValue;
+  DeviceGuard guard;
+  const int rc = h->settle();
+  if (rc) return rc;
+  unsigned long long total = 0;
+  for (Dev &v : h->d) {
+    FDTD_HIP_CHECK(hipSetDevice(v.id));
+    unsigned long long *acc = (unsigned long long *)v.reduce;
+    FDTD_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(unsigned long long), v.edge));
+    hipLaunchKernelGGL(word_sum_kernel, dim3(2048), dim3(256), 0, v.edge,
+                       (const unsigned *)(v.lv[ring_slot] + (size_t)FDTD_HALO * h->plane), (size_t)v.nx * h->plane, acc);
+    FDTD_HIP_CHECK(hipGetLastError());
+    unsigned long long out = 0;
+    FDTD_HIP_CHECK(hipMemcpyAsync(&out, acc, sizeof(out), hipMemcpyDeviceToHost, v.edge));
+    FDTD_HIP_CHECK(hipStreamSynchronize(v.edge));
+    total += out;
+  }
+  *sum = total;
   return 0;
 }
 

@@ -406,6 +406,9 @@ int fdtd_hip_one_step_slab(const struct fdtd_geom *g, const float *m, const floa
  *   gather   one ring slot (0 .. 2; slot t % 3 holds the newest level u(t), t = the session's time index)
  *            into a host array of nxp*nyp*nzp floats.
  *   max_abs  max |u| of the newest level and its number of NaN / Inf values, reduced on the devices.
+ *   checksum the sum of all 32-bit words of one ring slot's level as a 64-bit integer (order-independent, so the
+ *            same for every decomposition of the same run): compares a run on N slabs with the undivided one
+ *            without a host copy of either.
  *   stats    see fdtd_multigpu.hip: slabs, operations, host issue and wait time per operation, schedule.
  * Every function returns 0 or a positive hipError_t; after a failed advance the session only accepts
  * destroy.  Calls on one session must not overlap. */
@@ -425,6 +428,7 @@ int fdtd_hip_multigpu_set_damping(fdtd_multigpu *h, const float *damp);
 int fdtd_hip_multigpu_advance(fdtd_multigpu *h, int time_m, int time_M, struct profiler *timers);
 int fdtd_hip_multigpu_gather(fdtd_multigpu *h, int ring_slot, float *host_level);
 int fdtd_hip_multigpu_max_abs(fdtd_multigpu *h, float *max_abs, long *nonfinite);
+int fdtd_hip_multigpu_checksum(fdtd_multigpu *h, int ring_slot, unsigned long long *sum);
 int fdtd_hip_multigpu_stats(fdtd_multigpu *h, double out[10], int reset);
 
 /* fdtd_hip_two_steps_slab without the work-space argument, for callers that cannot allocate

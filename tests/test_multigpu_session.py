@@ -124,6 +124,26 @@ def test_session_with_damping(pkg, hiplib, n, slabs, zone_fused, monkeypatch):
     assert ob.bits_equal(got, plain)
 
 
+def test_checksum_is_the_same_for_every_decomposition(pkg, hiplib):
+    """Full-width slabs (512 x 512 cross-section, the benchmark inputs made on the devices): 1, 2 and 4 slabs give the
+    same 64-bit word sums of all three ring slots and the same max |u|, and the sum is the host's sum of the gathered
+    field — the check the full-size runs rely on (profiles/r03_config5_checksums_one_gpu.txt)."""
+    n, nt = (128, 512, 512), 24
+    sums, maxes = [], []
+    for slabs in (1, 2, 4):
+        with pkg.MultiGpuSession(_geom(pkg, n), [0] * slabs) as s:
+            s.fill_standard_inputs(nt + 1, 1)
+            s.advance(0, nt - 1)
+            sums.append(s.checksum())
+            maxes.append(s.max_abs())
+            if slabs == 4:
+                got = np.empty((3, n[0] + 8, n[1] + 8, n[2] + 8), dtype=np.float32)
+                s.gather(got)
+    assert sums[0] == sums[1] == sums[2] and maxes[0] == maxes[1] == maxes[2] and maxes[0][0] > 0
+    host = [int(got[slot][4:-4].view(np.uint32).astype(np.uint64).sum()) & 0xFFFFFFFFFFFFFFFF for slot in range(3)]
+    assert host == sums[2]
+
+
 def test_session_rejects_bad_arguments(pkg, hiplib):
     n = (32, 16, 64)
     g = _geom(pkg, n)
