@@ -31,6 +31,24 @@ def test_every_declared_symbol_is_exported(hiplib):
         assert hasattr(hiplib, n), f"libfdtd_hip.so does not export {n}"
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/fdtd_abi.h is the boundary: it must compile as C11 and as C++17 on its own, at the default space order
+    and with the padding macro set the way the reference driver sets STENCIL_ORDER (main.cpp:27-32)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    prog = tmp_path / "use_abi.c"
+    prog.write_text('#include "fdtd_abi.h"\n'
+                    'int halo(void) { struct fdtd_geom g = {0}; struct profiler t = {0, 0}; (void)g; (void)t; return FDTD_HALO; }\n')
+    inc = os.path.join(ROOT, "include")
+    for extra in ([], ["-DFDTD_STENCIL_ORDER=8"]):
+        subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-c", "-I", inc, str(prog), "-o",
+                        str(tmp_path / "a.o")] + extra, check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-c", "-I", inc, str(prog), "-o",
+                    str(tmp_path / "b.o")], check=True)
+
+
 def test_struct_layout_matches_reference(pkg):
     # main.cpp:35-50: nine pointer-sized fields, two doubles
     assert C.sizeof(pkg.Dataobj) == 72
