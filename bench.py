@@ -708,6 +708,9 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "frac_basis": "achieved / peak, with `achieved` as defined by achieved_basis (algorithmic bytes); the bytes that "
+                      "actually cross the fabric are `traffic`, their rate `physical_GBps` and its share of the peak "
+                      "`physical_frac`",
         "traffic": None,
         "avg_kernel_ms": round(kernel_ms, 4),
         "compulsory_bytes_per_launch": compulsory,
