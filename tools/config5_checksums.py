@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Config 5 at its full size and step count on one GPU: the 2048^3 grid, 200 steps, as 8 slabs (the 8-GPU schedule with
 every push a device-to-device copy) and undivided; the 64-bit word sums of the three newest levels and max |u| must be
-the same.  Nothing of the field leaves the device.
+the same.  A third run doubles the source: the update is linear and a factor of two is exact in binary32, so max |u|
+must double exactly.  Nothing of the field leaves the device.
 
     python tools/config5_checksums.py [--grid 2048] [--steps 200] [--slabs 8]
 """
@@ -39,7 +40,16 @@ def main():
         out.append((sums, mx, bad))
     same = out[0] == out[1]
     print("same field on both decompositions:", same)
-    sys.exit(0 if same and out[0][2] == 0 and out[0][1] > 0 else 1)
+    # linearity: twice the source, twice the field (exact: every operation of the update commutes with a factor of 2)
+    with pkg.MultiGpuSession(g, [0] * args.slabs) as s:
+        s.fill_standard_inputs(args.steps + 1, 1)
+        src = pkg.fill_ricker(args.steps + 1, 1) * 2.0
+        s.set_sources(src.astype("float32"), pkg.fill_source_coords(1, n, n, n))
+        s.advance(0, args.steps - 1)
+        mx2, bad2 = s.max_abs()
+    linear = bad2 == 0 and mx2 == 2.0 * out[0][1]
+    print(f"source doubled: max|u| {mx2:.9e} = 2 x {out[0][1]:.9e}: {linear}")
+    sys.exit(0 if same and linear and out[0][2] == 0 and out[0][1] > 0 else 1)
 
 
 if __name__ == "__main__":
