@@ -54,6 +54,9 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int M2_ROWS = 8;        // output rows per tile
 constexpr int M2_ZCELLS = 512;    // z extent
 constexpr int M2_MAX_SRC = 8;     // 8 corners each: one lane per corner
+#ifndef FDTD_FUSE2_SHARE_ROWS
+#define FDTD_FUSE2_SHARE_ROWS 1
+#endif
 
 struct Coef2 { float cm2, cm1, c0, dt2, r1, r2, r3, r4, neg2r1, dt, r0; };   // dt, r0 = 1/dt: damped form only
 
@@ -211,6 +214,16 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   const bool ld_out1 = LPR == 64 ? out1 : (MASK && __ballot(out1) != 0);
   const int yhalo = q < 2 ? yb - 4 + q : yb + 8 + q;   // B row outside the 12-row stack
   const int hslot = q < 2 ? q : 12 + q;
+  // Two tiles of 256-cell rows stacked in a workgroup: rows 6, 7 of the lower tile are the redundant rows below the
+  // upper one, and rows 0, 1 of the upper tile the redundant rows above the lower one.  The wave that owns such a
+  // row as an outer output row writes its B and its C into the sibling tile's LDS slots as well, and the sibling's
+  // wave does not load or compute that row (nor the B row two further out, which only it needed): 4 of the 8
+  // waves carry two row segments instead of three.  FDTD_FUSE2_SHARE_ROWS = 0 at compile time keeps every tile
+  // on its own.
+  constexpr bool SHARE = ZH == 1 && LPR == 64 && FDTD_FUSE2_SHARE_ROWS;
+  const bool skip2 = SHARE && ((h == 0 && q >= 2) || (h == 1 && q < 2));   // wave-uniform
+  const int dslot = h == 0 ? q - 2 : 10 + q;            // the sibling's C slot of this wave's outer output row
+  const int dcol = h == 0 ? 64 + lane : lane;           // ... in the sibling's columns
   const int lc = h * 64 + lane;                         // this lane's column in the LDS rows
   const int lz = ZH == 2 ? lc : zl;                     // float4 index inside the row of cells
   const bool seam_lane = (lz == 0 && cut_l) || (lz == TILE_F4 - 1 && cut_r);   // next to a z-cut
@@ -328,6 +341,14 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   f32x4 ch;           // C row of the redundant segment when that row is outside the domain, plane p
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
+    if (s == 2 && skip2) {   // the sibling tile supplies this row
+#pragma unroll
+      for (int i = 0; i < 5; ++i) bc[i][s] = f32x4{0, 0, 0, 0};
+      av[s] = mv[s] = f32x4{0, 0, 0, 0};
+      be[s] = f32x2{0, 0};
+      if constexpr (DAMP) dv[s] = f32x4{0, 0, 0, 0};
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) bc[i][s] = LD4(rB, (sp + (i - 2) * sxb) + rowoff[s], vzs[s]);
     if (LPR == 64) {
@@ -352,14 +373,19 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
     if constexpr (DAMP) dh[0][s] = dh[1][s] = f32x4{0, 0, 0, 0};
     ce[s] = f32x2{0, 0};
   }
-  bh = LD4(rB, (sp + sxb) + rowoff_h, vzh);
-  bh2 = LD4(rB, (sp + 2 * sxb) + rowoff_h, vzh);
-  ch = ld_seg2 ? LD4(rC, sp + rowoff[2], vzs[2]) : f32x4{0, 0, 0, 0};
+  bh = bh2 = ch = f32x4{0, 0, 0, 0};
+  if (!skip2) {
+    bh = LD4(rB, (sp + sxb) + rowoff_h, vzh);
+    bh2 = LD4(rB, (sp + 2 * sxb) + rowoff_h, vzh);
+    if (ld_seg2) ch = LD4(rC, sp + rowoff[2], vzs[2]);
+  }
   {  // B(p0): own rows and the outside row
     const int buf = p0 & 1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) Bbuf[buf][cslot[s] + 2][lc] = bc[2][s];
-    Bbuf[buf][hslot][lc] = LD4(rB, sp + rowoff_h, vzh);
+    for (int s = 0; s < 3; ++s)
+      if (!(s == 2 && skip2)) Bbuf[buf][cslot[s] + 2][lc] = bc[2][s];
+    if (skip2) Bbuf[buf][dslot + 2][dcol] = bc[2][1];
+    else Bbuf[buf][hslot][lc] = LD4(rB, sp + rowoff_h, vzh);
   }
   __syncthreads();
   int ring_w = ((p0 % 3) + 3) % 3;        // ring slot written this iteration (plane p)
@@ -387,6 +413,9 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
 
     auto compute = [&](auto seg) __attribute__((always_inline)) {
       constexpr int s = decltype(seg)::value;
+      if constexpr (s == 2 && SHARE) {
+        if (skip2) return;
+      }
       const int r = cslot[s];   // the row's slot in Bbuf is r + 2
       // ---- C(p) ----
       f32x4 cnew;
@@ -411,6 +440,9 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
         else if (!STEADY && !store_c && !row_out && plane_inside && seam_lane) st4<false>(rC, sp + rowoff[s], vzs[s], cnew);
       }
       Cring[ring_w][r][lc] = cnew;
+      if constexpr (s == 1 && SHARE) {
+        if (skip2) Cring[ring_w][dslot][dcol] = cnew;   // the sibling tile's redundant row
+      }
       // ---- D(p-2) ----
       if constexpr (s < 2) {
         if (do_d) {
@@ -449,10 +481,16 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
     // advance the B ring of a segment and reload what plane p+1 needs
     auto reload = [&](auto seg) __attribute__((always_inline)) {
       constexpr int s = decltype(seg)::value;
+      if constexpr (s == 2 && SHARE) {
+        if (skip2) return;
+      }
       const int r = cslot[s];
       if constexpr (s < 2) ce[s] = LD2(rC, (sq - 2 * sxb) + rowoff[s], vzcs[s]);   // C array, plane (p+1)-2
       if (STEADY) {
         Bbuf[buf ^ 1][r + 2][lc] = PB(3)[s];           // B(p+1), centre plane of the next iteration
+        if constexpr (s == 1 && SHARE) {
+          if (skip2) Bbuf[buf ^ 1][dslot + 2][dcol] = PB(3)[s];
+        }
         PB(0)[s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vzs[s]);     // B(p+3) replaces B(p-2)
       } else {
         bc[0][s] = bc[1][s];
@@ -460,6 +498,9 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
         bc[2][s] = bc[3][s];
         bc[3][s] = bc[4][s];
         Bbuf[buf ^ 1][r + 2][lc] = bc[2][s];
+        if constexpr (s == 1 && SHARE) {
+          if (skip2) Bbuf[buf ^ 1][dslot + 2][dcol] = bc[2][s];
+        }
         bc[4][s] = LD4(rB, (sq + 2 * sxb) + rowoff[s], vzs[s]);
       }
       if (LPR == 64) {
@@ -488,10 +529,12 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
     reload(S2{});
     compute(S0{});
     reload(S0{});
-    Bbuf[buf ^ 1][hslot][lc] = bh;
-    bh = bh2;
-    bh2 = LD4(rB, (sq + 2 * sxb) + rowoff_h, vzh);
-    if (ld_seg2) ch = LD4(rC, sq + rowoff[2], vzs[2]);
+    if (!skip2) {
+      Bbuf[buf ^ 1][hslot][lc] = bh;
+      bh = bh2;
+      bh2 = LD4(rB, (sq + 2 * sxb) + rowoff_h, vzh);
+      if (ld_seg2) ch = LD4(rC, sq + rowoff[2], vzs[2]);
+    }
     __syncthreads();
     ring_w = ring_w == 2 ? 0 : ring_w + 1;
     ring_r = ring_r == 2 ? 0 : ring_r + 1;

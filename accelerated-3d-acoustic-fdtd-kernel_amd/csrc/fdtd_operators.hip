@@ -54,15 +54,16 @@ struct EventPool {
 // unit, because three events per unit cost about 11 us per unit on the stream — a tenth of a
 // step at 256^3.  stride 1 (windows of up to 8 units, or FDTD_TIMER_STRIDE=1) records every
 // unit and sums the intervals themselves, which is what the reference's wrappers do
-// (cuda.cu:237-262 brackets each kernel); default stride 4.
+// (cuda.cu:237-262 brackets each kernel); default stride 4, and 12 where a unit is short (fewer than 80 M cell
+// updates, about 0.2 ms: at 256^3 a pair of steps takes 0.1 ms and a triple every fourth pair is 3 % of the window).
 struct SectionTimer {
   EventPool pool;
   int stride = 1, units = 0;
-  int init(int n_units) {
+  int init(int n_units, long cell_updates_per_unit = 0) {
     units = n_units;
     if (units <= 0) return 0;
     const char *e = getenv("FDTD_TIMER_STRIDE");
-    stride = e ? atoi(e) : (units <= 8 ? 1 : 4);
+    stride = e ? atoi(e) : (units <= 8 ? 1 : ((cell_updates_per_unit > 0 && cell_updates_per_unit < 80000000L) ? 12 : 4));
     if (stride < 1) stride = 1;
     return pool.make((size_t)((units + stride - 1) / stride) * 3 + 1);
   }
@@ -222,7 +223,8 @@ static int time_loop_fused(const struct fdtd_geom *g, const float *m, const floa
   // timed units: pairs, and a single step at the end of an odd window
   SectionTimer st;
   {
-    const int rc = st.init((n_timed + 1) / 2);
+    const long box = (long)(g->x_M - g->x_m + 1) * (g->y_M - g->y_m + 1) * (g->z_M - g->z_m + 1);
+    const int rc = st.init((n_timed + 1) / 2, 2 * box);
     if (rc) return rc;
   }
   int unit = 0;
