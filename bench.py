@@ -173,6 +173,11 @@ def measure_traffic(kernel_substr, launches_expected):
     prof = shutil.which("rocprofv3")
     if prof is None:
         return None
+    # already under a profiler (its settings would be inherited by the child runs and combined with the counter
+    # collection): leave the measurement to whoever is profiling
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None
     argv = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
     # strip the options this function sets itself
     clean, skip = [], 0
