@@ -653,6 +653,56 @@ __global__ __launch_bounds__(256) void seam_kernel(SeamArgs a) {
   *(Quad *)(a.D + i) = o;
 }
 
+// The same pass with the u(t+1) cells around the cut staged through LDS: a workgroup takes 32 rows x 8 planes of one
+// cut, loads the eight cells cut-4 .. cut+3 of every site of that patch grown by two rows and two planes (two aligned
+// 16-byte loads per site) and serves all x- and y-neighbours from there; only u(t), m (and the damping field) of the
+// four cells come from memory per thread.  4 instead of 13 scattered line requests per site; same operands in the same
+// order, hence the same bits.
+constexpr int SEAM_ROWS = 32, SEAM_PLANES = 8;
+template <bool DAMP>
+__global__ __launch_bounds__(256) void seam_tile_kernel(SeamArgs a, int x_M) {
+  __shared__ f32x4 cs[SEAM_PLANES + 4][SEAM_ROWS + 4][2];
+  const int ty = threadIdx.x % SEAM_ROWS, tp = threadIdx.x / SEAM_ROWS;
+  const int y0 = a.y_m + (int)blockIdx.x * SEAM_ROWS, x0 = a.x_m + (int)blockIdx.z * SEAM_PLANES;
+  const int zc = a.z_m + a.cut[blockIdx.y];   // first cell behind the cut
+  // rows and planes beyond the box repeat the last ones that exist around it; their values are never used
+  for (int i = threadIdx.x; i < (SEAM_PLANES + 4) * (SEAM_ROWS + 4); i += 256) {
+    const int pr = i / (SEAM_ROWS + 4), rr = i % (SEAM_ROWS + 4);
+    const int x = min(x0 - 2 + pr, x_M + 2), y = min(y0 - 2 + rr, a.y_M + 2);
+    const float *at = a.C + (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (zc - 4 + FDTD_HALO);
+    cs[pr][rr][0] = *(const f32x4 *)at;
+    cs[pr][rr][1] = *(const f32x4 *)(at + 4);
+  }
+  __syncthreads();
+  const int x = x0 + tp, y = y0 + ty;
+  if (x > x_M || y > a.y_M) return;
+  auto quad = [&](int pr, int rr) {   // cells cut-2 .. cut+1 of a site
+    const f32x4 lo = cs[pr][rr][0], hi = cs[pr][rr][1];
+    return f32x4{lo.z, lo.w, hi.x, hi.y};
+  };
+  const int pr = tp + 2, rr = ty + 2;
+  const f32x4 lo = cs[pr][rr][0], hi = cs[pr][rr][1];
+  const f32x4 c = f32x4{lo.z, lo.w, hi.x, hi.y};
+  const f32x2 zm = f32x2{lo.x, lo.y}, zp = f32x2{hi.z, hi.w};
+  const f32x4 xm2 = quad(pr - 2, rr), xm1 = quad(pr - 1, rr), xp1 = quad(pr + 1, rr), xp2 = quad(pr + 2, rr);
+  const f32x4 ym2 = quad(pr, rr - 2), ym1 = quad(pr, rr - 1), yp1 = quad(pr, rr + 1), yp2 = quad(pr, rr + 2);
+  const long i = (long)(x + FDTD_HALO) * a.sx + (long)(y + FDTD_HALO) * a.sy + (zc - 2 + FDTD_HALO);
+  auto ld = [](const float *p, long at) {
+    const Quad q = *(const Quad *)(p + at);
+    return f32x4{q.v[0], q.v[1], q.v[2], q.v[3]};
+  };
+  const f32x4 up = ld(a.B, i), mc = ld(a.m, i);
+  const f32x4 dc = DAMP ? ld(a.damp, i) : f32x4{0, 0, 0, 0};
+  const f32x2 cl = lo2(c), ch = hi2(c);
+  const f32x2 o0 = update_pair<DAMP>(a.k, cl, lo2(xm2), lo2(xm1), lo2(xp1), lo2(xp2), lo2(ym2), lo2(ym1), lo2(yp1),
+                                     lo2(yp2), zm + ch, f32x2{zm.y + c.y, c.x + c.z}, lo2(up), lo2(mc), lo2(dc));
+  const f32x2 o1 = update_pair<DAMP>(a.k, ch, hi2(xm2), hi2(xm1), hi2(xp1), hi2(xp2), hi2(ym2), hi2(ym1), hi2(yp1),
+                                     hi2(yp2), cl + zp, f32x2{c.y + c.w, c.z + zp.x}, hi2(up), hi2(mc), hi2(dc));
+  Quad o;
+  o.v[0] = o0.x; o.v[1] = o0.y; o.v[2] = o1.x; o.v[3] = o1.y;
+  *(Quad *)(a.D + i) = o;
+}
+
 // More than 8 sources do not fit the sweep's one-lane-per-corner scatter.  The sweep then runs
 // without sources, the first scatter is applied to the C level in memory afterwards, and this
 // kernel recomputes D on the cells whose stencil contains a scattered cell: the 13 cells of the
@@ -1167,16 +1217,26 @@ int fdtd_two_steps_impl(const struct fdtd_geom *g, const float *m, const float *
     sa.C = next1; sa.B = cur; sa.m = m; sa.D = next2; sa.damp = damp;
     sa.sx = a.sx; sa.sy = a.sy; sa.x_m = g->x_m; sa.y_m = g->y_m; sa.y_M = g->y_M; sa.z_m = g->z_m;
     sa.k = a.k;
-    // eight cuts per launch; grid.z is limited to 65535 planes
+    // eight cuts per launch; grid.z is limited to 65535 (planes, or groups of 8 planes)
+    const bool tiled = env_int2("FDTD_SEAM_TILE", 1) != 0 && (((uintptr_t)next1) % 16 == 0) && a.sx % 4 == 0 && a.sy % 4 == 0 &&
+                       g->z_m % 4 == 0;
     for (int c0 = 1; c0 < nzt; c0 += 8) {
       const int ncut = nzt - c0 < 8 ? nzt - c0 : 8;
       for (int i = 0; i < ncut; ++i) sa.cut[i] = zstep ? (c0 + i) * zstep : tl.mixed.zoff[c0 + i];
-      for (int x0 = g->x_m; x0 <= g->x_M; x0 += 65535) {
+      const int span = tiled ? 65535 * SEAM_PLANES : 65535;
+      for (int x0 = g->x_m; x0 <= g->x_M; x0 += span) {
         sa.x_m = x0;
-        const int planes = g->x_M - x0 + 1 < 65535 ? g->x_M - x0 + 1 : 65535;
-        const dim3 sgrid((unsigned)((ey + 255) / 256), (unsigned)ncut, (unsigned)planes);
-        if (damp) hipLaunchKernelGGL(seam_kernel<true>, sgrid, dim3(256), 0, s, sa);
-        else hipLaunchKernelGGL(seam_kernel<false>, sgrid, dim3(256), 0, s, sa);
+        const int planes = g->x_M - x0 + 1 < span ? g->x_M - x0 + 1 : span;
+        if (tiled) {
+          const dim3 sgrid((unsigned)((ey + SEAM_ROWS - 1) / SEAM_ROWS), (unsigned)ncut,
+                           (unsigned)((planes + SEAM_PLANES - 1) / SEAM_PLANES));
+          if (damp) hipLaunchKernelGGL(seam_tile_kernel<true>, sgrid, dim3(256), 0, s, sa, x0 + planes - 1);
+          else hipLaunchKernelGGL(seam_tile_kernel<false>, sgrid, dim3(256), 0, s, sa, x0 + planes - 1);
+        } else {
+          const dim3 sgrid((unsigned)((ey + 255) / 256), (unsigned)ncut, (unsigned)planes);
+          if (damp) hipLaunchKernelGGL(seam_kernel<true>, sgrid, dim3(256), 0, s, sa);
+          else hipLaunchKernelGGL(seam_kernel<false>, sgrid, dim3(256), 0, s, sa);
+        }
       }
     }
   }
