@@ -44,6 +44,9 @@
 #include "fdtd_device.h"
 
 namespace {
+#ifdef FDTD_WG_CLOCKS
+__device__ unsigned long long g_wg_clock[11][1024];
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -56,6 +59,9 @@ constexpr int M2_ZCELLS = 512;    // z extent
 constexpr int M2_MAX_SRC = 8;     // 8 corners each: one lane per corner
 #ifndef FDTD_FUSE2_SHARE_ROWS
 #define FDTD_FUSE2_SHARE_ROWS 1
+#endif
+#ifndef FDTD_FUSE2_MIRROR_FIRST_TILE
+#define FDTD_FUSE2_MIRROR_FIRST_TILE 1
 #endif
 
 struct Coef2 { float cm2, cm1, c0, dt2, r1, r2, r3, r4, neg2r1, dt, r0; };   // dt, r0 = 1/dt: damped form only
@@ -194,7 +200,15 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   const int zl = LPR == 64 ? lane : (lane & 31);     // position inside the row part
   const int half = LPR == 64 ? 0 : (lane >> 5);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = wave & 1, q = wave >> 1;
+  // Which waves take which rows: the wave pair w = wave >> 1 takes row role q = w, except in the first y-tile of
+  // the box when the tile is 512 cells wide, where the roles are mirrored (q = 3 - w).  In the first and in the last
+  // y-tile two of the four roles carry a row outside the box (kept as memory holds it, not computed).  Measured on
+  // MI355X with a time stamp per workgroup (FDTD_WG_CLOCKS, tools/wg_clocks.py): a workgroup whose older waves
+  // (0 .. 3) have those roles takes 4-5 % longer per plane than every other workgroup of the launch, whichever end of
+  // the box it sits at, and a launch lasts as long as its slowest workgroup (512^3: 586 -> 566 us per sweep).
+  // Mirrored, the younger waves have them, as in the last y-tile.  Tiles of 256 and 128 cells showed no such tail.
+  const bool flip = FDTD_FUSE2_MIRROR_FIRST_TILE && ZH == 2 && yt == 0;
+  const int h = wave & 1, q = flip ? 3 - (wave >> 1) : (wave >> 1);
   const int yb = a.y_m + (ZH == 2 ? yt * M2_ROWS : (LPR == 64 ? (2 * yt + h) : (4 * yt + 2 * h + half)) * M2_ROWS);
   const int x_begin = a.x_m + xc * xchunk;
   const int x_end = min(x_begin + xchunk - 1, a.x_M);
@@ -554,6 +568,9 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
     iteration(std::integral_constant<int, 2>{}, T{}, p + 2);
     iteration(std::integral_constant<int, 3>{}, T{}, p + 3);
     iteration(std::integral_constant<int, 4>{}, T{}, p + 4);
+#ifdef FDTD_WG_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[3 + min((p - x_begin) / 16, 7)][blockIdx.x] = wall_clock64();
+#endif
   }
   for (; p <= p_last; ++p) iteration(std::integral_constant<int, 0>{}, F{}, p);
 #undef LD4
@@ -568,9 +585,26 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
   constexpr int TILE_CELLS = ZH == 2 ? M2_ZCELLS : LPR * 4;
+#ifdef FDTD_WG_CLOCKS
+  const int t_orig = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
+  const int t = t_orig;
+#else
   const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
+#endif
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
+#ifdef FDTD_WG_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[0][blockIdx.x] = wall_clock64();
+#endif
   march2_tile<NT, ZH, MASK, LPR, DAMP>(a, xchunk, a.z_m + zt * TILE_CELLS, zt > 0, zt < nzt - 1, yt, xc, Bbuf, Cring);
+#ifdef FDTD_WG_CLOCKS
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_wg_clock[1][blockIdx.x] = wall_clock64();
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_wg_clock[2][blockIdx.x] = ((unsigned long long)xcc << 32) | (unsigned)t;
+  }
+#endif
 }
 
 // Mixed tiling: a row is covered by z-tiles of different kinds — tiles of 512 cells first, then one of 256,
@@ -802,6 +836,11 @@ int env_int2(const char *name, int fallback) {
 }
 
 }  // namespace
+#ifdef FDTD_WG_CLOCKS
+extern "C" int fdtd_debug_wg_clocks(unsigned long long *out) {   // 3 x 1024 values of the last launch
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_clock), sizeof(unsigned long long) * 11 * 1024);
+}
+#endif
 
 // How the (y, z) cross-section of a box is cut into tiles: uniform z-tiles of 512, 256 or 128 cells
 // (8, 16 or 32 rows per workgroup), or the mixed tiling; a cross-section that does not fill its tiles
