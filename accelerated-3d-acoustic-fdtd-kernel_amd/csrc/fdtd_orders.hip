@@ -106,6 +106,27 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nblocks) {   // workgro
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+// FDTD_WG_CLOCKS (a measurement build, `make clocks`): a time stamp per workgroup of the marching sweeps at its
+// start and at its end, read back through fdtd_debug_wg_clocks_orders (tools/wg_clocks.py --order).
+#ifdef FDTD_WG_CLOCKS
+__device__ unsigned long long g_order_clock[3][4096];
+struct WgClock {
+  int tile;
+  __device__ explicit WgClock(int t) : tile(t) {
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_order_clock[0][blockIdx.x] = wall_clock64();
+  }
+  __device__ ~WgClock() {
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+      g_order_clock[1][blockIdx.x] = wall_clock64();
+      g_order_clock[2][blockIdx.x] = (unsigned long long)tile;
+    }
+  }
+};
+#define WG_CLOCK(t) WgClock wg_clock_(t)
+#else
+#define WG_CLOCK(t)
+#endif
+
 // LPR = lanes per row: 64 (tiles of 256 cells) or 32 (tiles of 128 cells: a wave then carries two rows per
 // row slot and the tile has twice as many rows), for rows that fill multiples of 128 cells better.
 template <int R, int RW, int D, bool NT, bool DAMPED = false, int LPR = 64>
@@ -125,6 +146,7 @@ __global__ __launch_bounds__(512) void stencil_order_march_kernel(StencilArgs a,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane % LPR, sub = lane / LPR;   // float4 of the row, row of the row slot
   const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  WG_CLOCK(t);
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nzt * nyt);
   const int zb = a.z_m + zt * TZ, yb = a.y_m + yt * TY;
   const int x_begin = a.x_m + xc * xchunk, x_end = min(x_begin + xchunk - 1, a.x_M);
@@ -360,6 +382,7 @@ __global__ __launch_bounds__(512) void stencil_column_march_kernel(StencilArgs a
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+  WG_CLOCK(t);
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nzt * nyt);
   const int yb = a.y_m + yt * TY, y0 = yb + wave * RY;
   const int zfirst = a.z_m + zt * TZ + lane * 4;
@@ -649,6 +672,12 @@ bool order_march_takes(const StencilArgs &a, int H) {
 }
 
 }  // namespace
+
+#ifdef FDTD_WG_CLOCKS
+extern "C" int fdtd_debug_wg_clocks_orders(unsigned long long *out) {   // 3 x 4096 values of the last launch
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_order_clock), sizeof(unsigned long long) * 3 * 4096);
+}
+#endif
 
 extern "C" int fdtd_hip_set_space_order(int order) {
   if (!order_supported(order)) return (int)hipErrorInvalidValue;
