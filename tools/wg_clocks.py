@@ -24,7 +24,7 @@ extra = torch.zeros_like(u_d[0]); P = [u_d[0], u_d[1], u_d[2], extra]
 cur, prev, third, spare = 0, 2, 1, 3
 sh = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 L.fdtd_debug_wg_clocks.argtypes = [C.c_void_p]; L.fdtd_debug_wg_clocks.restype = C.c_int
-out = np.zeros((11, 1024), dtype=np.uint64)
+out = np.zeros((14, 1024), dtype=np.uint64)
 for t in range(0, steps, 2):
     rc = L.fdtd_hip_two_steps_ex(C.byref(g), m_d.data_ptr(), s_d.data_ptr(), c_d.data_ptr(), P[cur].data_ptr(), P[prev].data_ptr(),
                                  P[third].data_ptr(), P[spare].data_ptr(), t, 0, 0, 1, 3, -1, 1, None, None, sh)
@@ -48,3 +48,6 @@ for t in range(0, steps, 2):
         ph = (out[3:11, :nwg].astype(np.int64) - t0) / 100.0
         for name, sel in (("tile0", (tile % ntile) == 0), ("tile63", (tile % ntile) == ntile - 1), ("others", ((tile % ntile) > 4) & ((tile % ntile) < ntile - 5))):
             print("  ", name, "time at the end of each 16-plane bucket:", " ".join(f"{np.median(ph[b][sel]):.0f}" for b in range(8)))
+        ph2 = (out[11:14, :nwg].astype(np.int64) - t0) / 100.0
+        print(f"   medians: prologue done {np.median(ph2[0] - st):.1f} us after start, lead-in (4 planes) {np.median(ph2[1] - ph2[0]):.1f} us, "
+              f"steady planes {np.median(ph2[2] - ph2[1]):.1f} us, tail planes {np.median(en - ph2[2]):.1f} us")
