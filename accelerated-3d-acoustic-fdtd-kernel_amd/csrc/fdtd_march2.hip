@@ -44,6 +44,9 @@
 #include "fdtd_device.h"
 
 namespace {
+// FDTD_WG_CLOCKS (a measurement build, `make clocks`): time stamps of every workgroup of stencil_march2_kernel, read back
+// through fdtd_debug_wg_clocks (tools/wg_clocks.py).  Rows: 0 start, 1 end, 2 XCC id << 32 | tile, 3 .. 10 the last stamp
+// taken in each 16-plane bucket of the steady planes, 11 prologue done, 12 lead-in done, 13 steady planes done.
 #ifdef FDTD_WG_CLOCKS
 __device__ unsigned long long g_wg_clock[14][1024];
 #endif
@@ -606,12 +609,7 @@ __global__ __launch_bounds__(512) void stencil_march2_kernel(March2Args a, int x
   __shared__ f32x4 Bbuf[2][16][128];
   __shared__ f32x4 Cring[3][12][128];
   constexpr int TILE_CELLS = ZH == 2 ? M2_ZCELLS : LPR * 4;
-#ifdef FDTD_WG_CLOCKS
-  const int t_orig = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
-  const int t = t_orig;
-#else
   const int t = wg_base + xcd_contiguous_tile(blockIdx.x, gridDim.x);
-#endif
   const int zt = t % nzt, yt = (t / nzt) % nyt, xc = t / (nyt * nzt);
 #ifdef FDTD_WG_CLOCKS
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[0][blockIdx.x] = wall_clock64();
@@ -858,7 +856,7 @@ int env_int2(const char *name, int fallback) {
 
 }  // namespace
 #ifdef FDTD_WG_CLOCKS
-extern "C" int fdtd_debug_wg_clocks(unsigned long long *out) {   // 3 x 1024 values of the last launch
+extern "C" int fdtd_debug_wg_clocks(unsigned long long *out) {   // 14 x 1024 values of the last launch
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_clock), sizeof(unsigned long long) * 14 * 1024);
 }
 #endif
