@@ -15,7 +15,9 @@ neighbours as RCCL point-to-point messages.  Default: the multi-GPU configuratio
 2048^3 grid split into N x-slabs (strong scaling); --weak gives every rank --grid planes instead.
 `python bench.py --gpus N` starts its own N ranks (child processes, started before this process
 touches the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it
-is one of the ranks.
+is one of the ranks.  After that run rank 0, when it sees N GPUs, measures the same workload through the
+library's one-process multi-device session (ghost planes pushed by the copy engines) in a process of its
+own; the line carries both runs and `value` is the faster one (peer_leg below says why).
 
 Protocol: the reference driver repeats every configuration 5 times and reports mean and population
 standard deviation (main.cpp:99-111,388).  Here a repetition zeroes the wavefield, does W untimed
@@ -392,6 +394,67 @@ def peer_main(args):
     }
     print(json.dumps(out))
     return 0
+
+
+def peer_leg(args, out, world):
+    """After the ranks' run over RCCL, rank 0 measures the same workload through the library's multi-device session
+    (one process, ghost planes pushed by the copy engines) in a process of its own, and the line carries both.
+
+    Why both: RCCL's send/receive kernel needs compute units of its own (64 workgroups of 132 registers per lane; it
+    cannot share a CU with a workgroup of the two-step sweep), and a sweep launch of 256 workgroups that finds some CUs
+    taken needs a second round for the displaced ones.  With messages to itself on one GPU that costs 3 % of a step;
+    between GPUs the kernel lives as long as the transfer takes on the link.  The copy engines take no CUs.  `value` is
+    the faster of the two runs; `config.transport` says which, `ranks_over_rccl` / `one_process_peer_copies` hold both.
+    FDTD_BENCH_PEER_LEG=0: the RCCL run only; =force: also when this process sees fewer GPUs than ranks (rehearsal)."""
+    mode = os.environ.get("FDTD_BENCH_PEER_LEG", "1")
+    rccl = {"value": out["value"], "ms_per_step": out["ms_per_step"], "transport": out["exchange"]["transport"],
+            "Mcells_per_s": out["reps"]["Mcells_per_s"]}
+    out["ranks_over_rccl"] = rccl
+    out["config"]["transport"] = "rccl"
+    if mode == "0":
+        return
+    import torch
+    if mode != "force" and torch.cuda.device_count() < world:
+        out["one_process_peer_copies"] = {"skipped": f"this process sees {torch.cuda.device_count()} GPU(s), the run has {world} ranks"}
+        return
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME",
+                        "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FDTD_BENCH_BACKEND")
+           and not k.startswith("TORCHELASTIC_")}
+    argv = [sys.executable, os.path.abspath(__file__), "--transport", "peer", "--gpus", str(world), "--steps", str(args.steps),
+            "--warmup", str(args.warmup), "--reps", str(args.reps), "--no-breakdown"]
+    if args.grid:
+        argv += ["--grid", str(args.grid)]
+    if args.global_x:
+        argv += ["--global-x", str(args.global_x)]
+    if args.weak:
+        argv += ["--weak"]
+    try:
+        p = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=float(os.environ.get("FDTD_BENCH_PEER_LEG_TIMEOUT", "900")))
+        lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            tail = p.stderr.decode(errors="replace").strip().splitlines()[-3:]
+            out["one_process_peer_copies"] = {"failed": f"exit code {p.returncode}", "stderr_tail": tail}
+            return
+        peer = json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        out["one_process_peer_copies"] = {"failed": "time limit"}
+        return
+    out["one_process_peer_copies"] = {"value": peer["value"], "ms_per_step": peer["ms_per_step"],
+                                      "Mcells_per_s": peer["reps"]["Mcells_per_s"], "workload": peer["config"]["workload"],
+                                      "exchange": peer.get("exchange", {})}
+    if peer["value"] > out["value"]:
+        for k in ("value", "ms_per_step", "effective_GBps_at_algorithmic_bytes", "reps", "roofline", "exchange"):
+            if k in peer:
+                out[k] = peer[k]
+        out["config"]["workload"] = peer["config"]["workload"]
+        out["config"]["transport"] = "peer copies (one process)"
+        out["config"]["ranks"] = peer["config"]["ranks"]
+        out["config"]["slabs"] = peer["config"]["slabs"]
 
 
 def run_both(args):
@@ -801,6 +864,9 @@ def main():
         out["exchange"] = exchange
     if slabs and world == 1:
         out["config"]["workload"] += " [one rank, own neighbour on both sides: schedule rehearsal]"
+    if slabs and world > 1 and not h16:
+        prop = stepper = tmax = None      # this rank's arrays go before another process allocates its slabs on the device
+        peer_leg(args, out, world)
     if world == 1 and not slabs and not args.no_cpu_baseline and args.space_order == 4:
         out["cpu_baseline"] = cpu_baseline(pkg, n, args.cpu_steps)
     print(json.dumps(out))

@@ -35,6 +35,8 @@ def test_bench_starts_its_own_ranks():
     assert out["scaling"] == "strong" and out["steps"] == 6 and out["reps"]["n"] == 2
     assert out["value"] > 0 and "128x512x512" in out["config"]["workload"]
     assert "exchange" in out
+    assert out["config"]["transport"] == "rccl" and out["ranks_over_rccl"]["value"] == out["value"]
+    assert "skipped" in out["one_process_peer_copies"]      # one GPU visible, two ranks
 
 
 @pytest.mark.gpu
@@ -57,6 +59,28 @@ def test_bench_under_the_distributed_launcher():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and "96x512x512" in out["config"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_ranks_then_the_one_process_session():
+    """After the ranks' run, rank 0 measures the same workload through the multi-device session in a process of its own;
+    the line carries both and `value` is the faster one.  (Forced here: the box has one GPU, the ranks share it and so
+    do the session's slabs.  By default the second run happens when rank 0 sees as many GPUs as there are ranks.)"""
+    env = dict(os.environ, FDTD_BENCH_BACKEND="gloo", FDTD_BENCH_PEER_LEG="force")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--grid", "512", "--global-x", "128", "--steps", "6",
+                        "--warmup", "2", "--reps", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    both = (out["ranks_over_rccl"], out["one_process_peer_copies"])
+    assert both[0]["value"] > 0 and both[1]["value"] > 0, both
+    assert "128x512x512" in both[1]["workload"]
+    assert out["value"] == max(b["value"] for b in both)
+    assert out["config"]["transport"] == ("rccl" if both[0]["value"] >= both[1]["value"] else "peer copies (one process)")
+    assert out["n_gpus"] == 2 and out["steps"] == 6
 
 
 @pytest.mark.gpu
