@@ -434,7 +434,7 @@ def peer_leg(args, out, world):
         argv += ["--weak"]
     try:
         p = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                           timeout=float(os.environ.get("FDTD_BENCH_PEER_LEG_TIMEOUT", "900")))
+                           timeout=float(os.environ.get("FDTD_BENCH_PEER_LEG_TIMEOUT", "240")))
         lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not lines:
             tail = p.stderr.decode(errors="replace").strip().splitlines()[-3:]
