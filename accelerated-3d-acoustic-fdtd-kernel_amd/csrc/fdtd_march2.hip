@@ -119,9 +119,15 @@ __device__ __forceinline__ f32x4 ld4(rsrc_t r, int soff, unsigned voff) {
 __device__ __forceinline__ f32x2 ld2(rsrc_t r, int soff, unsigned voff) {
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
 }
+// The scalar offset is folded into the lane offset and the instruction's own scalar-offset field stays zero.  With a
+// register there, the compiler follows the gfx9 rule that a 16-byte buffer store needs no wait state before the next
+// vector instruction overwrites its data registers, and schedules such a write directly behind the store.  On MI355X
+// that lost data: in one build a ring move followed the store of u(t+2) and some lanes stored the moved values in
+// the upper half of the float4 (the cells of a row's 13th to 16th lanes of every 16, run to run).  With an immediate
+// zero the compiler inserts the wait state itself whenever a following instruction writes the store's registers.
 template <bool NT>
 __device__ __forceinline__ void st4(rsrc_t r, int soff, unsigned voff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, soff, NT ? 2 : 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(voff + (unsigned)soff), 0, NT ? 2 : 0);
 }
 
 // One row segment, 4 cells per lane, evaluated on register pairs: a float4 lives in four
@@ -196,7 +202,7 @@ __device__ __forceinline__ f32x4 update_seg(const Coef2 &k, f32x4 c, f32x4 xm2, 
 // serve the seam pass).  The kernels below map workgroups to tiles.
 typedef f32x4 (&BbufRef)[2][16][128];
 typedef f32x4 (&CringRef)[3][12][128];
-template <bool NT, int ZH, bool MASK, int LPR, bool DAMP>
+template <bool NT, int ZH, bool MASK, int LPR, bool DAMP, bool ALONE = true>
 __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int zb, bool cut_l, bool cut_r, int yt,
                                             int xc, BbufRef Bbuf, CringRef Cring) {
   static_assert(LPR == 64 || (LPR == 32 && ZH == 1), "half-wave tiles exist for rows of 128 cells only");
@@ -241,6 +247,9 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   // waves carry two row segments instead of three.  FDTD_FUSE2_SHARE_ROWS = 0 at compile time keeps every tile
   // on its own.
   constexpr bool SHARE = ZH == 1 && LPR == 64 && FDTD_FUSE2_SHARE_ROWS;
+  // (two copies of the checked form: see `checked` below.  The pairs of 256-cell tiles need the most registers; next to the
+  // other tile kinds in the mixed kernel two copies of them spill, so there they keep one.)
+  constexpr bool SPLIT_OK = ALONE || !(ZH == 1 && LPR == 64);
   const bool skip2 = SHARE && ((h == 0 && q >= 2) || (h == 1 && q < 2));   // wave-uniform
   const int dslot = h == 0 ? q - 2 : 10 + q;            // the sibling's C slot of this wave's outer output row
   const int dcol = h == 0 ? 64 + lane : lane;           // ... in the sibling's columns
@@ -414,7 +423,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
   // One plane.  STEADY: plane inside the box and the chunk, second step active, no branch around
   // a memory instruction, ring phase J.  Otherwise (J = 0): every condition checked, rings
   // advanced by register moves.
-  auto iteration = [&](auto phase, auto steady, int p) __attribute__((always_inline)) {
+  auto iteration = [&](auto phase, auto steady, auto inside, int p) __attribute__((always_inline)) {
     constexpr int J = decltype(phase)::value;
     constexpr bool STEADY = decltype(steady)::value;
 #define PB(i) bc[(J + (i)) % 5]
@@ -422,7 +431,10 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
     const int buf = p & 1;
     const bool more = STEADY ? true : p < p_last;
     const int sq = sp + (more ? sxb : 0);   // plane p+1 (repeats plane p at the very end)
-    const bool plane_inside = STEADY ? true : (p >= a.dx_m && p <= a.dx_M);
+    // inside: 1 = the plane lies inside the domain, 0 = it is one of the domain's halo planes (its u(t+1) is what memory
+    // holds), 2 = decided here at run time
+    constexpr int INSIDE = decltype(inside)::value;
+    const bool plane_inside = STEADY || (INSIDE == 2 ? (p >= a.dx_m && p <= a.dx_M) : INSIDE == 1);
     const bool store_c = STEADY ? true
                                 : (plane_inside && ((p >= x_begin && p <= x_end) || (a.keep_lo && p < a.x_m) ||
                                                     (a.keep_hi && p > a.x_M)));
@@ -578,17 +590,27 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
 #ifdef FDTD_WG_CLOCKS
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[11][blockIdx.x] = wall_clock64();   // prologue done
 #endif
-  for (; p < x_begin + 2 && p <= p_last; ++p) iteration(std::integral_constant<int, 0>{}, F{}, p);
+  // The checked form comes in two copies, for planes inside the domain and for its halo planes, whose u(t+1) is loaded
+  // instead of computed: with both in one copy every use of the row waits for a load that may just have been issued
+  // (seven full waits per plane).  256^3 358 against 348 Gcells/s, 384^3 356 against 347.5, 768^3 446.6 against 443.7.
+  // The damped variants keep one copy that decides at run time: two would not fit their registers.
+  auto checked = [&](int pl) __attribute__((always_inline)) {
+    using P0 = std::integral_constant<int, 0>;
+    if constexpr (DAMP || !SPLIT_OK) iteration(P0{}, F{}, std::integral_constant<int, 2>{}, pl);
+    else if (pl >= a.dx_m && pl <= a.dx_M) iteration(P0{}, F{}, std::integral_constant<int, 1>{}, pl);
+    else iteration(P0{}, F{}, std::integral_constant<int, 0>{}, pl);
+  };
+  for (; p < x_begin + 2 && p <= p_last; ++p) checked(p);
 #ifdef FDTD_WG_CLOCKS
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[12][blockIdx.x] = wall_clock64();   // lead-in done
 #endif
   // steady state in groups of five planes, all of them inside [x_begin + 2, x_end - 1]
   for (; p + 4 <= x_end - 1; p += 5) {
-    iteration(std::integral_constant<int, 0>{}, T{}, p);
-    iteration(std::integral_constant<int, 1>{}, T{}, p + 1);
-    iteration(std::integral_constant<int, 2>{}, T{}, p + 2);
-    iteration(std::integral_constant<int, 3>{}, T{}, p + 3);
-    iteration(std::integral_constant<int, 4>{}, T{}, p + 4);
+    iteration(std::integral_constant<int, 0>{}, T{}, std::integral_constant<int, 1>{}, p);
+    iteration(std::integral_constant<int, 1>{}, T{}, std::integral_constant<int, 1>{}, p + 1);
+    iteration(std::integral_constant<int, 2>{}, T{}, std::integral_constant<int, 1>{}, p + 2);
+    iteration(std::integral_constant<int, 3>{}, T{}, std::integral_constant<int, 1>{}, p + 3);
+    iteration(std::integral_constant<int, 4>{}, T{}, std::integral_constant<int, 1>{}, p + 4);
 #ifdef FDTD_WG_CLOCKS
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[3 + min((p - x_begin) / 16, 7)][blockIdx.x] = wall_clock64();
 #endif
@@ -596,7 +618,7 @@ __device__ __forceinline__ void march2_tile(const March2Args &a, int xchunk, int
 #ifdef FDTD_WG_CLOCKS
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg_clock[13][blockIdx.x] = wall_clock64();   // steady planes done
 #endif
-  for (; p <= p_last; ++p) iteration(std::integral_constant<int, 0>{}, F{}, p);
+  for (; p <= p_last; ++p) checked(p);
 #undef LD4
 #undef LD4S
 #undef LD2
@@ -659,7 +681,7 @@ __global__ __launch_bounds__(512) void stencil_march2_mixed_kernel(March2Args a,
   const int yt = band * (4 >> kind) + s;        // y-tile index in units of this kind's rows per workgroup
   if (MASK && a.y_m + yt * (M2_ROWS << kind) > a.y_M) return;   // a workgroup wholly beyond the last row (last band)
   if (kind == 0) march2_tile<NT, 2, MASK, 64, DAMP>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
-  else if (kind == 1) march2_tile<NT, 1, MASK, 64, DAMP>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
+  else if (kind == 1) march2_tile<NT, 1, MASK, 64, DAMP, false>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
   else march2_tile<NT, 1, MASK, 32, DAMP>(a, xchunk, zb, cut_l, cut_r, yt, xc, Bbuf, Cring);
 }
 
