@@ -900,6 +900,8 @@ static M2Tiling m2_tiling(int ey, int ez) {
   // per plane-iteration, 256 workgroups at a time, i.e. 17.2 ns per workgroup and plane; one whose rows end
   // inside the tile less (4.0 us at three quarters: 0.7 + 0.3 x fill); one with four tiles of 128 cells 5.1
   // to 5.6 us (its row pieces are 512 bytes long); every z-cut adds a seam pass of 0.14 ns per row and plane.
+  // (Later kernels: 4.2 / 4.3 / 4.8 us per plane at 512 / 256 / 128 cells and a cheaper seam pass; the choices the model
+  // makes were measured again with them and are still the faster ones at 384, 640, 896 and 1152 cells per row.)
   constexpr double WG_NS = 17.2, NARROW = 1.3, SEAM_NS = 0.14;
   auto partial = [](int cells, int tile) { return 0.7 + 0.3 * (double)cells / tile; };
   auto make = [&](int zstep) {
