@@ -453,8 +453,9 @@ def peer_leg(args, out, world):
                 out[k] = peer[k]
         out["config"]["workload"] = peer["config"]["workload"]
         out["config"]["transport"] = "peer copies (one process)"
-        out["config"]["ranks"] = peer["config"]["ranks"]
-        out["config"]["slabs"] = peer["config"]["slabs"]
+        for k in ("ranks", "slabs"):
+            if k in peer["config"]:
+                out["config"][k] = peer["config"][k]
 
 
 def run_both(args):
@@ -866,7 +867,10 @@ def main():
         out["config"]["workload"] += " [one rank, own neighbour on both sides: schedule rehearsal]"
     if slabs and world > 1 and not h16:
         prop = stepper = tmax = None      # this rank's arrays go before another process allocates its slabs on the device
-        peer_leg(args, out, world)
+        try:
+            peer_leg(args, out, world)
+        except Exception as e:            # the second leg is extra evidence: it never takes the ranks' line with it
+            out["one_process_peer_copies"] = {"failed": f"{type(e).__name__}: {e}"}
     if world == 1 and not slabs and not args.no_cpu_baseline and args.space_order == 4:
         out["cpu_baseline"] = cpu_baseline(pkg, n, args.cpu_steps)
     print(json.dumps(out))
